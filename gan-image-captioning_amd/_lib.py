@@ -1,0 +1,150 @@
+"""ctypes binding of libgicap.so (C ABI declared in include/gicap.h).
+
+Fails loudly: there is no fallback implementation.  ``load()`` raises if the
+library has not been built (``python __graft_entry__.py`` / ``build.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+MAX_LAYERS = 4
+MAX_CONVS = 8
+F32, BF16 = 0, 1
+LOSS_TYPES = {"standard": 0, "JS": 1, "KL": 2, "hinge": 3, "tv": 4, "rsgan": 5}
+
+c_float_p = C.POINTER(C.c_float)
+c_void_p = C.c_void_p
+
+
+class DecoderDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "L", "V", "E", "H", "NL", "dtype")]
+
+
+class DecoderParams(C.Structure):
+    _fields_ = [("embed", c_void_p), ("w_ih", c_void_p * MAX_LAYERS), ("w_hh", c_void_p * MAX_LAYERS),
+                ("b_ih", c_void_p * MAX_LAYERS), ("b_hh", c_void_p * MAX_LAYERS), ("w_out", c_void_p), ("b_out", c_void_p)]
+
+
+class DecoderGrads(C.Structure):
+    _fields_ = DecoderParams._fields_ + [("features", c_void_p)]
+
+
+class DecoderShadow(C.Structure):
+    _fields_ = [("wcat", c_void_p * MAX_LAYERS), ("bsum", c_void_p * MAX_LAYERS), ("wout", c_void_p)]
+
+
+class DecoderState(C.Structure):
+    _fields_ = [("xh", c_void_p * MAX_LAYERS), ("gates", c_void_p * MAX_LAYERS), ("c", c_void_p * MAX_LAYERS),
+                ("hout", c_void_p), ("logits", c_void_p), ("gpre", c_void_p)]
+
+
+class DecoderBwdWs(C.Structure):
+    _fields_ = [("dlogits", c_void_p), ("dhout", c_void_p), ("dgates", c_void_p * MAX_LAYERS),
+                ("dxh", c_void_p * MAX_LAYERS), ("dc", c_void_p * MAX_LAYERS)]
+
+
+class DiscDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("V", C.c_int32), ("De", C.c_int32), ("R", C.c_int32),
+                ("nconv", C.c_int32), ("fsize", C.c_int32 * MAX_CONVS), ("nfilt", C.c_int32 * MAX_CONVS),
+                ("F", C.c_int32), ("Fp", C.c_int32), ("dtype", C.c_int32)]
+
+
+class DiscParams(C.Structure):
+    _fields_ = [("emb", c_void_p), ("conv_w", c_void_p * MAX_CONVS), ("conv_b", c_void_p * MAX_CONVS),
+                ("hw_w", c_void_p), ("hw_b", c_void_p), ("f2o_w", c_void_p), ("f2o_b", c_void_p),
+                ("o2l_w", c_void_p), ("o2l_b", c_void_p)]
+
+
+class DiscGrads(C.Structure):
+    _fields_ = DiscParams._fields_
+
+
+class DiscShadow(C.Structure):
+    _fields_ = [("emb", c_void_p), ("hw_w", c_void_p), ("f2o_w", c_void_p)]
+
+
+class DiscState(C.Structure):
+    _fields_ = [("emb", c_void_p), ("pooled", c_void_p), ("argmax", c_void_p), ("hpre", c_void_p),
+                ("keep", c_void_p), ("ydrop", c_void_p), ("feat", c_void_p)]
+
+
+class DiscBwdWs(C.Structure):
+    _fields_ = [("dfeat", c_void_p), ("dh", c_void_p), ("dydrop", c_void_p), ("dpooled", c_void_p), ("demb", c_void_p)]
+
+
+_P = C.POINTER
+_SIGNATURES = {
+    "gic_abi_version": (C.c_int, []),
+    "gic_last_error": (C.c_char_p, []),
+    "gic_gemm": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64,
+                           C.c_int, C.c_int, C.c_int, C.c_int, c_void_p, C.c_int, C.c_float, c_void_p]),
+    "gic_cast2d": (C.c_int, [c_void_p, C.c_int, C.c_int64, c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, c_void_p]),
+    "gic_decoder_prepare": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), c_void_p]),
+    "gic_decoder_sample_fwd": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), _P(DecoderState), c_void_p,
+                                         c_void_p, C.c_uint64, C.c_float, C.c_int, c_void_p, c_void_p, c_void_p]),
+    "gic_decoder_sample_bwd": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), _P(DecoderState),
+                                         _P(DecoderBwdWs), c_void_p, c_void_p, c_void_p, C.c_float, C.c_int,
+                                         _P(DecoderGrads), c_void_p]),
+    "gic_embedding_fwd": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, c_void_p]),
+    "gic_embedding_bwd": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int, c_void_p]),
+    "gic_disc_prepare": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), c_void_p]),
+    "gic_disc_fwd": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), _P(DiscState), c_void_p, C.c_int64, c_void_p,
+                               C.c_int, c_void_p, C.c_uint64, c_void_p, c_void_p]),
+    "gic_disc_bwd": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), _P(DiscState), _P(DiscBwdWs), c_void_p,
+                               C.c_int64, c_void_p, C.c_int, c_void_p, _P(DiscGrads), C.c_int, c_void_p, C.c_int64, c_void_p]),
+    "gic_gan_losses": (C.c_int, [C.c_int, c_void_p, c_void_p, c_void_p, C.c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p]),
+    "gic_xent": (C.c_int, [c_void_p, C.c_int, C.c_int64, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gic_clip_adam_partials": (C.c_int64, [C.c_int64]),
+    "gic_clip_adam": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+_lib = None
+
+
+class GicError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load() -> C.CDLL:
+    """Load libgicap.so; raise (never fall back) if it is missing or exports are incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise GicError(f"{path} not found: build it first (python __graft_entry__.py, or gan-image-captioning_amd/build.py); "
+                       "there is no CPU / eager fallback for the hot path")
+    lib = C.CDLL(path)
+    for name, (res, argtypes) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise GicError(f"{path} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = argtypes
+    if lib.gic_abi_version() != 1:
+        raise GicError(f"ABI version mismatch: library {lib.gic_abi_version()}, binding 1")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status == 0:
+        return
+    msg = load().gic_last_error().decode(errors="replace")
+    text = f"libgicap {what} failed with status {status}: {msg}"
+    if status == -1:
+        raise ValueError(text)
+    if status == -2:
+        raise NotImplementedError(text)
+    raise GicError(text)

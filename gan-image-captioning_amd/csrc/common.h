@@ -1,0 +1,130 @@
+// Shared device/host helpers for the gfx950 (MI355X) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gic {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum DType { DT_F32 = 0, DT_BF16 = 1 };
+
+static constexpr int WAVE = 64;   // CDNA wavefront
+
+// ---------------------------------------------------------------- status
+enum Status {
+  GIC_OK = 0,
+  GIC_ERR_INVALID_ARG = -1,
+  GIC_ERR_UNSUPPORTED = -2,
+  GIC_ERR_LAUNCH = -3,
+  GIC_ERR_WORKSPACE = -4,
+};
+
+void set_last_error(const char* fmt, ...);
+
+#define GIC_CHECK_ARG(cond, ...)                       \
+  do {                                                 \
+    if (!(cond)) {                                     \
+      ::gic::set_last_error(__VA_ARGS__);              \
+      return ::gic::GIC_ERR_INVALID_ARG;               \
+    }                                                  \
+  } while (0)
+
+#define GIC_CHECK_LAUNCH(what)                                                     \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      ::gic::set_last_error("%s: launch failed: %s", what, hipGetErrorString(e__)); \
+      return ::gic::GIC_ERR_LAUNCH;                                                \
+    }                                                                              \
+  } while (0)
+
+#define GIC_PROPAGATE(expr)        \
+  do {                             \
+    int s__ = (expr);              \
+    if (s__ != ::gic::GIC_OK) return s__; \
+  } while (0)
+
+// ---------------------------------------------------------------- scalar load/store across dtypes
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float ld_as_f32(const void* p, long i, int dtype) {
+  return dtype == DT_F32 ? ((const float*)p)[i] : (float)((const bf16_t*)p)[i];
+}
+__device__ __forceinline__ void st_from_f32(void* p, long i, int dtype, float v) {
+  if (dtype == DT_F32) ((float*)p)[i] = v; else ((bf16_t*)p)[i] = (bf16_t)v;
+}
+__host__ __device__ __forceinline__ int dtype_size(int dtype) { return dtype == DT_F32 ? 4 : 2; }
+
+// ---------------------------------------------------------------- wave / block reductions (wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum, result valid in every thread. `red` = LDS scratch of >= 16 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = red[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// ---------------------------------------------------------------- counter-based RNG (Philox4x32-10)
+// Used for on-device Gumbel uniforms and dropout masks in perf mode; parity
+// mode passes explicit noise instead (CPU MT19937 != any device generator).
+struct Philox {
+  __host__ __device__ static inline void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  }
+  // 4 x 32 random bits for (seed, stream, index)
+  __host__ __device__ static inline void gen(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      round(c, k0, k1);
+      k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+  }
+  // U[0,1) with 24 bits, like torch's float uniform_
+  __host__ __device__ static inline float u01(uint32_t bits) { return (bits >> 8) * (1.0f / 16777216.0f); }
+};
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace gic

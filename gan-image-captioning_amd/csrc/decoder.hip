@@ -1,0 +1,384 @@
+// Generator hot loop: Decoder.sample forward / backward (reference src/generator.py:55-96).
+//
+// Layout (DESIGN.md "decoder"): the recurrent side is time-major -- per layer one
+// XH buffer [(L+1), B, Din+H] holding [LSTM input | previous hidden] so that step t's
+// gate GEMM reads one contiguous [B, Din+H] operand and the batched wgrad reads one
+// [L*B, Din+H] operand; the vocabulary side (probs, d_probs, d_logits, hout) is
+// batch-major [B, L, .] like the tensors the reference returns.  The pointwise kernels
+// bridge the two with explicit strides.
+#include "../../include/gicap.h"
+#include "kernels.h"
+
+namespace gic {
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ---- LSTM pointwise forward: gates pre-activation [B,4H] (i,f,g,o blocks) -> gates, c, h (3 destinations)
+template <typename TA>
+__global__ void lstm_pointwise_fwd_kernel(const float* __restrict__ gpre, const float* __restrict__ c_prev,
+                                          float* __restrict__ gates, float* __restrict__ c_new,
+                                          TA* __restrict__ h_next, long ld_next,      // XH_l[t+1][:, Din:]
+                                          TA* __restrict__ h_up, long ld_up,          // XH_{l+1}[t][:, :H] or null
+                                          TA* __restrict__ h_out, long ld_out,        // hout[b, t, :] or null
+                                          int B, int H) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * H) return;
+  const int b = idx / H, j = idx % H;
+  const float* g = gpre + (long)b * 4 * H;
+  const float i_ = sigmoidf_(g[j]);
+  const float f_ = sigmoidf_(g[H + j]);
+  const float g_ = tanhf(g[2 * H + j]);
+  const float o_ = sigmoidf_(g[3 * H + j]);
+  const float c = f_ * c_prev[idx] + i_ * g_;
+  const float h = o_ * tanhf(c);
+  float* go = gates + (long)b * 4 * H;
+  go[j] = i_; go[H + j] = f_; go[2 * H + j] = g_; go[3 * H + j] = o_;
+  c_new[idx] = c;
+  h_next[(long)b * ld_next + j] = from_f32<TA>(h);
+  if (h_up) h_up[(long)b * ld_up + j] = from_f32<TA>(h);
+  if (h_out) h_out[(long)b * ld_out + j] = from_f32<TA>(h);
+}
+
+// ---- LSTM pointwise backward for one (layer, step)
+template <typename TA>
+__global__ void lstm_pointwise_bwd_kernel(const float* __restrict__ dh_a, long ld_a,   // d h from above (dhout[b,t,:] or upper layer dx)
+                                          const float* __restrict__ dh_b, long ld_b,   // recurrent d h from step t+1 (or null)
+                                          const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                          const float* __restrict__ c_cur, float* __restrict__ dc_state,
+                                          TA* __restrict__ dgates, int B, int H) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * H) return;
+  const int b = idx / H, j = idx % H;
+  float dh = dh_a[(long)b * ld_a + j];
+  if (dh_b) dh += dh_b[(long)b * ld_b + j];
+  const float* g = gates + (long)b * 4 * H;
+  const float i_ = g[j], f_ = g[H + j], g_ = g[2 * H + j], o_ = g[3 * H + j];
+  const float tc = tanhf(c_cur[idx]);
+  const float dc = dc_state[idx] + dh * o_ * (1.f - tc * tc);
+  TA* dg = dgates + (long)b * 4 * H;
+  dg[j] = from_f32<TA>(dc * g_ * i_ * (1.f - i_));
+  dg[H + j] = from_f32<TA>(dc * c_prev[idx] * f_ * (1.f - f_));
+  dg[2 * H + j] = from_f32<TA>(dc * i_ * (1.f - g_ * g_));
+  dg[3 * H + j] = from_f32<TA>(dh * tc * o_ * (1.f - o_));
+  dc_state[idx] = dc * f_;
+}
+
+// ---- per-row Gumbel-softmax + argmax + next-input embedding gather (generator.py:68-76, 84-96)
+// One 256-thread block per batch row.  y = (o + g) * T is written back over the logits scratch,
+// then exp / sum / normalise; argmax over the stored probabilities with first-index tie-break.
+template <typename TA>
+__global__ __launch_bounds__(256) void gumbel_softmax_argmax_kernel(
+    float* __restrict__ logits, const float* __restrict__ u, uint64_t seed, uint64_t rng_stream, float temperature,
+    int pretrain, TA* __restrict__ out, long out_row_stride, int64_t* __restrict__ ids, long ids_stride,
+    const float* __restrict__ embed, TA* __restrict__ x_next, long ld_x, int V, int E) {
+  __shared__ float red[16];
+  __shared__ int red_i[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float* row = logits + (long)b * V;
+  TA* orow = out + (long)b * out_row_stride;
+  const float eps = 1e-10f;
+
+  // pass 1: y, row max
+  float mx = -INFINITY;
+  for (int v = tid; v < V; v += 256) {
+    float y = row[v];
+    if (!pretrain) {
+      float uu;
+      if (u) {
+        uu = u[(long)b * V + v];
+      } else {
+        uint32_t r[4];
+        const uint64_t idx = (uint64_t)b * (uint64_t)V + (uint64_t)v;
+        Philox::gen(seed, rng_stream, idx >> 2, r);
+        uu = Philox::u01(r[idx & 3]);
+      }
+      const float g = -logf(-logf(uu + eps) + eps);
+      y = (y + g) * temperature;
+      row[v] = y;
+    }
+    mx = fmaxf(mx, y);
+  }
+  mx = block_max(mx, red);
+  // pass 2: exp, sum
+  float sm = 0.f;
+  for (int v = tid; v < V; v += 256) sm += expf(row[v] - mx);
+  sm = block_sum(sm, red);
+  // pass 3: probabilities, argmax (first maximal index), output
+  float best = -1.f;
+  int best_i = 0x7fffffff;
+  for (int v = tid; v < V; v += 256) {
+    const float y = row[v];
+    const float p = expf(y - mx) / sm;
+    orow[v] = from_f32<TA>(pretrain ? y : p);
+    if (p > best) { best = p; best_i = v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(best_i, o, 64);
+    if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+  }
+  if ((tid & 63) == 0) { red[tid >> 6] = best; red_i[tid >> 6] = best_i; }
+  __syncthreads();
+  best = red[0]; best_i = red_i[0];
+  for (int w = 1; w < 4; ++w)
+    if (red[w] > best || (red[w] == best && red_i[w] < best_i)) { best = red[w]; best_i = red_i[w]; }
+  if (tid == 0) ids[(long)b * ids_stride] = best_i;
+  if (x_next)
+    for (int e = tid; e < E; e += 256) x_next[(long)b * ld_x + e] = from_f32<TA>(embed[(long)best_i * E + e]);
+}
+
+// ---- softmax backward: dlogit = T * p * (dp - sum(dp*p))   (one block per (b,t) row)
+template <typename TA>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const TA* __restrict__ p, const TA* __restrict__ dp,
+                                                           TA* __restrict__ dl, float temperature, int V) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const TA* pr = p + row * V;
+  const TA* dr = dp + row * V;
+  float s = 0.f;
+  for (int v = threadIdx.x; v < V; v += 256) s += to_f32<TA>(pr[v]) * to_f32<TA>(dr[v]);
+  s = block_sum(s, red);
+  for (int v = threadIdx.x; v < V; v += 256) {
+    const float pv = to_f32<TA>(pr[v]);
+    dl[row * V + v] = from_f32<TA>(temperature * pv * (to_f32<TA>(dr[v]) - s));
+  }
+}
+
+// Wcat = [w_ih | w_hh] in the compute dtype, bsum = b_ih + b_hh
+template <typename TA>
+__global__ void build_wcat_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                  const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                  TA* __restrict__ wcat, float* __restrict__ bsum, int rows, int din, int hid) {
+  const long ld = din + hid;
+  const long total = (long)rows * ld;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / ld;
+    const int c = (int)(i % ld);
+    const float v = c < din ? w_ih[r * din + c] : w_hh[r * hid + (c - din)];
+    wcat[i] = from_f32<TA>(v);
+    if (c == 0) bsum[r] = b_ih[r] + b_hh[r];
+  }
+}
+
+struct Ctx {
+  int B, L, V, E, H, NL, dt;
+  int din(int l) const { return l == 0 ? E : H; }
+  long ldx(int l) const { return (long)din(l) + H; }
+  size_t asz() const { return (size_t)dtype_size(dt); }
+};
+
+int check_dims(const gic_decoder_dims* d, Ctx& c) {
+  GIC_CHECK_ARG(d, "decoder: null dims");
+  GIC_CHECK_ARG(d->B > 0 && d->L > 0 && d->V > 1 && d->E > 0 && d->H > 0, "decoder: bad dims");
+  GIC_CHECK_ARG(d->NL >= 1 && d->NL <= GIC_MAX_LAYERS, "decoder: gen_num_layers must be 1..%d", GIC_MAX_LAYERS);
+  GIC_CHECK_ARG(d->dtype == DT_F32 || d->dtype == DT_BF16, "decoder: bad dtype");
+  c = Ctx{d->B, d->L, d->V, d->E, d->H, d->NL, d->dtype};
+  return GIC_OK;
+}
+
+template <typename TA>
+int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_shadow* S, const gic_decoder_state* st,
+                 const float* features, const float* noise_u, uint64_t seed, float temperature, int pretrain,
+                 void* out, int64_t* ids, hipStream_t stream) {
+  const int B = c.B, L = c.L, V = c.V, E = c.E, H = c.H, NL = c.NL;
+  const int pw_grid = cdiv((long)B * H, 256);
+  // slot 0: zero hidden / cell state, features -> layer-0 input
+  for (int l = 0; l < NL; ++l) {
+    GIC_PROPAGATE(fill_zero(st->xh[l], (size_t)B * c.ldx(l) * c.asz(), stream));
+    GIC_PROPAGATE(fill_zero(st->c[l], (size_t)B * H * sizeof(float), stream));
+  }
+  GIC_PROPAGATE(cast2d(features, DT_F32, E, st->xh[0], c.dt, c.ldx(0), B, E, stream));
+
+  for (int t = 0; t < L; ++t) {
+    for (int l = 0; l < NL; ++l) {
+      const long ld = c.ldx(l);
+      TA* xh_t = (TA*)st->xh[l] + (long)t * B * ld;
+      TA* xh_n = (TA*)st->xh[l] + (long)(t + 1) * B * ld;
+      GemmDesc g;
+      g.A = xh_t; g.lda = ld; g.B = S->wcat[l]; g.ldb = ld; g.C = st->gpre; g.ldc = 4 * H;
+      g.M = B; g.N = 4 * H; g.K = (int)ld; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.bias = S->bsum[l];
+      GIC_PROPAGATE(gemm(g, stream));
+      TA* h_up = (l + 1 < NL) ? (TA*)st->xh[l + 1] + (long)t * B * c.ldx(l + 1) : nullptr;
+      TA* h_out = (l + 1 == NL) ? (TA*)st->hout + (long)t * H : nullptr;
+      hipLaunchKernelGGL((lstm_pointwise_fwd_kernel<TA>), dim3(pw_grid), dim3(256), 0, stream,
+                         (const float*)st->gpre, (const float*)(st->c[l] + (long)t * B * H),
+                         st->gates[l] + (long)t * B * 4 * H, st->c[l] + (long)(t + 1) * B * H,
+                         xh_n + c.din(l), ld, h_up, h_up ? c.ldx(l + 1) : 0, h_out, (long)L * H, B, H);
+      GIC_CHECK_LAUNCH("lstm_pointwise_fwd");
+    }
+    {  // vocabulary projection on the last layer's h_t (lives in XH_last[t+1][:, Din:])
+      const int l = NL - 1;
+      const long ld = c.ldx(l);
+      GemmDesc g;
+      g.A = (TA*)st->xh[l] + (long)(t + 1) * B * ld + c.din(l); g.lda = ld;
+      g.B = S->wout; g.ldb = H; g.C = st->logits; g.ldc = V;
+      g.M = B; g.N = V; g.K = H; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.bias = P->b_out;
+      GIC_PROPAGATE(gemm(g, stream));
+    }
+    TA* x_next = (TA*)st->xh[0] + (long)(t + 1) * B * c.ldx(0);
+    hipLaunchKernelGGL((gumbel_softmax_argmax_kernel<TA>), dim3(B), dim3(256), 0, stream, st->logits,
+                       noise_u ? noise_u + (long)t * B * V : nullptr, seed, (uint64_t)t, temperature, pretrain,
+                       (TA*)out + (long)t * V, (long)L * V, ids + t, (long)L, P->embed, x_next, c.ldx(0), V, E);
+    GIC_CHECK_LAUNCH("gumbel_softmax_argmax");
+  }
+  return GIC_OK;
+}
+
+template <typename TA>
+int sample_bwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_shadow* S, const gic_decoder_state* st,
+                 const gic_decoder_bwd_ws* ws, const void* probs, const int64_t* ids, const void* d_out,
+                 float temperature, int pretrain, const gic_decoder_grads* G, hipStream_t stream) {
+  const int B = c.B, L = c.L, V = c.V, E = c.E, H = c.H, NL = c.NL;
+  const long BL = (long)B * L;
+  const int pw_grid = cdiv((long)B * H, 256);
+  // 1. d_logits [B,L,V]
+  const void* dlog = d_out;
+  if (!pretrain) {
+    hipLaunchKernelGGL((softmax_bwd_kernel<TA>), dim3((unsigned)BL), dim3(256), 0, stream, (const TA*)probs,
+                       (const TA*)d_out, (TA*)ws->dlogits, temperature, V);
+    GIC_CHECK_LAUNCH("softmax_bwd");
+    dlog = ws->dlogits;
+  }
+  // 2. d_hout = d_logits W_out ; dW_out = d_logits^T hout ; db_out = colsum(d_logits)
+  {
+    GemmDesc g;
+    g.A = dlog; g.lda = V; g.a_kc = 1; g.B = S->wout; g.ldb = H; g.b_kc = 0; g.C = ws->dhout; g.ldc = H;
+    g.M = (int)BL; g.N = H; g.K = V; g.in_dtype = c.dt; g.out_dtype = DT_F32;
+    GIC_PROPAGATE(gemm(g, stream));
+    GemmDesc w;
+    w.A = dlog; w.lda = V; w.a_kc = 0; w.B = st->hout; w.ldb = H; w.b_kc = 0; w.C = G->w_out; w.ldc = H;
+    w.M = V; w.N = H; w.K = (int)BL; w.in_dtype = c.dt; w.out_dtype = DT_F32;
+    GIC_PROPAGATE(gemm(w, stream));
+    GIC_PROPAGATE(colsum(dlog, c.dt, V, BL, V, G->b_out, nullptr, 0, stream));
+  }
+  // 3. BPTT
+  for (int l = 0; l < NL; ++l) {
+    GIC_PROPAGATE(fill_zero(ws->dc[l], (size_t)B * H * sizeof(float), stream));
+    GIC_PROPAGATE(fill_zero(ws->dxh[l] + (long)L * B * c.ldx(l), (size_t)B * c.ldx(l) * sizeof(float), stream));
+  }
+  for (int t = L - 1; t >= 0; --t) {
+    for (int l = NL - 1; l >= 0; --l) {
+      const long ld = c.ldx(l);
+      const float* dh_a;
+      long ld_a;
+      if (l == NL - 1) { dh_a = ws->dhout + (long)t * H; ld_a = (long)L * H; }
+      else { dh_a = ws->dxh[l + 1] + (long)t * B * c.ldx(l + 1); ld_a = c.ldx(l + 1); }
+      const float* dh_b = ws->dxh[l] + (long)(t + 1) * B * ld + c.din(l);
+      TA* dg = (TA*)ws->dgates[l] + (long)t * B * 4 * H;
+      hipLaunchKernelGGL((lstm_pointwise_bwd_kernel<TA>), dim3(pw_grid), dim3(256), 0, stream, dh_a, ld_a, dh_b, ld,
+                         (const float*)(st->gates[l] + (long)t * B * 4 * H), (const float*)(st->c[l] + (long)t * B * H),
+                         (const float*)(st->c[l] + (long)(t + 1) * B * H), ws->dc[l], dg, B, H);
+      GIC_CHECK_LAUNCH("lstm_pointwise_bwd");
+      GemmDesc g;   // d[x | h_prev] = d_gates Wcat
+      g.A = dg; g.lda = 4 * H; g.a_kc = 1; g.B = S->wcat[l]; g.ldb = ld; g.b_kc = 0;
+      g.C = ws->dxh[l] + (long)t * B * ld; g.ldc = ld;
+      g.M = B; g.N = (int)ld; g.K = 4 * H; g.in_dtype = c.dt; g.out_dtype = DT_F32;
+      GIC_PROPAGATE(gemm(g, stream));
+    }
+  }
+  // 4. batched weight gradients over all L*B rows
+  for (int l = 0; l < NL; ++l) {
+    const long ld = c.ldx(l);
+    GemmDesc w;
+    w.A = ws->dgates[l]; w.lda = 4 * H; w.a_kc = 0; w.b_kc = 0; w.ldb = ld;
+    w.M = 4 * H; w.K = (int)BL; w.in_dtype = c.dt; w.out_dtype = DT_F32;
+    w.B = st->xh[l]; w.N = c.din(l); w.C = G->w_ih[l]; w.ldc = c.din(l);
+    GIC_PROPAGATE(gemm(w, stream));
+    w.B = (const TA*)st->xh[l] + c.din(l); w.N = H; w.C = G->w_hh[l]; w.ldc = H;
+    GIC_PROPAGATE(gemm(w, stream));
+    GIC_PROPAGATE(colsum(ws->dgates[l], c.dt, 4 * H, BL, 4 * H, G->b_ih[l], G->b_hh[l], 0, stream));
+  }
+  // 5. inputs: d_features = dx_0 ; d_embed[ids[b,t-1]] += dx_t (t >= 1)  (generator.py:75: index detached)
+  GIC_PROPAGATE(cast2d(ws->dxh[0], DT_F32, c.ldx(0), G->features, DT_F32, E, B, E, stream));
+  GIC_PROPAGATE(fill_zero(G->embed, (size_t)V * E * sizeof(float), stream));
+  // the scatter-add itself (embed_scatter_time_kernel) is enqueued by the caller below
+  return GIC_OK;
+}
+
+__global__ void embed_scatter_time_kernel(const float* __restrict__ dxh0, long ld, const int64_t* __restrict__ ids,
+                                          float* __restrict__ dw, int B, int L, int E, int V) {
+  const long total = (long)(L - 1) * B * E;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i % E);
+    const long r = i / E;
+    const int b = (int)(r % B);
+    const int t = (int)(r / B) + 1;
+    long id = ids[(long)b * L + (t - 1)];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    atomicAdd(&dw[id * E + e], dxh0[((long)t * B + b) * ld + e]);
+  }
+}
+
+}  // namespace
+}  // namespace gic
+
+using namespace gic;
+
+extern "C" {
+
+int gic_decoder_prepare(const gic_decoder_dims* dims, const gic_decoder_params* P, const gic_decoder_shadow* S, void* stream_) {
+  Ctx c;
+  GIC_PROPAGATE(check_dims(dims, c));
+  GIC_CHECK_ARG(P && S, "decoder_prepare: null struct");
+  hipStream_t stream = (hipStream_t)stream_;
+  for (int l = 0; l < c.NL; ++l) {
+    GIC_CHECK_ARG(P->w_ih[l] && P->w_hh[l] && P->b_ih[l] && P->b_hh[l] && S->wcat[l] && S->bsum[l], "decoder_prepare: null layer %d", l);
+    const long total = (long)4 * c.H * c.ldx(l);
+    const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    if (c.dt == DT_F32)
+      hipLaunchKernelGGL((build_wcat_kernel<float>), dim3(grid), dim3(256), 0, stream, P->w_ih[l], P->w_hh[l], P->b_ih[l],
+                         P->b_hh[l], (float*)S->wcat[l], S->bsum[l], 4 * c.H, c.din(l), c.H);
+    else
+      hipLaunchKernelGGL((build_wcat_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, P->w_ih[l], P->w_hh[l], P->b_ih[l],
+                         P->b_hh[l], (bf16_t*)S->wcat[l], S->bsum[l], 4 * c.H, c.din(l), c.H);
+    GIC_CHECK_LAUNCH("build_wcat");
+  }
+  GIC_CHECK_ARG(P->w_out && S->wout, "decoder_prepare: null w_out");
+  if ((const void*)S->wout != (const void*)P->w_out)
+    GIC_PROPAGATE(cast2d(P->w_out, DT_F32, c.H, S->wout, c.dt, c.H, c.V, c.H, stream));
+  return GIC_OK;
+}
+
+int gic_decoder_sample_fwd(const gic_decoder_dims* dims, const gic_decoder_params* P, const gic_decoder_shadow* S,
+                           const gic_decoder_state* st, const float* features, const float* noise_u, uint64_t seed,
+                           float temperature, int pretrain, void* out, int64_t* ids, void* stream) {
+  Ctx c;
+  GIC_PROPAGATE(check_dims(dims, c));
+  GIC_CHECK_ARG(P && S && st && features && out && ids, "decoder_sample_fwd: null argument");
+  GIC_CHECK_ARG(st->hout && st->logits && st->gpre, "decoder_sample_fwd: null state buffer");
+  for (int l = 0; l < c.NL; ++l)
+    GIC_CHECK_ARG(st->xh[l] && st->gates[l] && st->c[l] && S->wcat[l] && S->bsum[l], "decoder_sample_fwd: null layer %d buffer", l);
+  if (c.dt == DT_F32)
+    return sample_fwd_t<float>(c, P, S, st, features, noise_u, seed, temperature, pretrain, out, ids, (hipStream_t)stream);
+  return sample_fwd_t<bf16_t>(c, P, S, st, features, noise_u, seed, temperature, pretrain, out, ids, (hipStream_t)stream);
+}
+
+int gic_decoder_sample_bwd(const gic_decoder_dims* dims, const gic_decoder_params* P, const gic_decoder_shadow* S,
+                           const gic_decoder_state* st, const gic_decoder_bwd_ws* ws, const void* probs,
+                           const int64_t* ids, const void* d_out, float temperature, int pretrain,
+                           const gic_decoder_grads* G, void* stream_) {
+  Ctx c;
+  GIC_PROPAGATE(check_dims(dims, c));
+  GIC_CHECK_ARG(P && S && st && ws && probs && ids && d_out && G, "decoder_sample_bwd: null argument");
+  GIC_CHECK_ARG(ws->dlogits && ws->dhout && G->embed && G->w_out && G->b_out && G->features, "decoder_sample_bwd: null buffer");
+  for (int l = 0; l < c.NL; ++l)
+    GIC_CHECK_ARG(ws->dgates[l] && ws->dxh[l] && ws->dc[l] && G->w_ih[l] && G->w_hh[l] && G->b_ih[l] && G->b_hh[l],
+                  "decoder_sample_bwd: null layer %d buffer", l);
+  hipStream_t stream = (hipStream_t)stream_;
+  int s = (c.dt == DT_F32)
+              ? sample_bwd_t<float>(c, P, S, st, ws, probs, ids, d_out, temperature, pretrain, G, stream)
+              : sample_bwd_t<bf16_t>(c, P, S, st, ws, probs, ids, d_out, temperature, pretrain, G, stream);
+  GIC_PROPAGATE(s);
+  if (c.L > 1) {
+    const long total = (long)(c.L - 1) * c.B * c.E;
+    const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(embed_scatter_time_kernel, dim3(grid), dim3(256), 0, stream, (const float*)ws->dxh[0], c.ldx(0), ids,
+                       G->embed, c.B, c.L, c.E, c.V);
+    GIC_CHECK_LAUNCH("embed_scatter_time");
+  }
+  return GIC_OK;
+}
+
+}  // extern "C"

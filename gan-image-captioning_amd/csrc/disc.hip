@@ -1,0 +1,434 @@
+// Sequence discriminator: Discriminator.forward / backward (reference src/discriminator.py:34-62).
+//
+//   emb[B*L,De] = inp W_emb^T (MFMA GEMM, or a gather when the input is token ids)
+//   pooled[B*R,F] = max_t relu(conv_f(emb))   fused conv+bias+ReLU+max-over-time: the
+//                   [B,300,L-f+1,64] pre-pool tensor of the reference is never materialised;
+//                   one block per (b, representation) stages its L x s window in LDS
+//   highway       = GEMM with fused gate + dropout epilogue (EPI_HIGHWAY)
+//   head          = GEMM 900->100, then a 100-wide dot per row
+// Activations [B*R, Fp] keep a zero-padded leading dim Fp (multiple of 8) so the bf16 GEMMs
+// can use 16-byte chunks along K; pad columns are zero (written by these kernels or, for
+// `ydrop`, left from a zero-initialised allocation - the GEMM epilogue never touches them).
+#include "../../include/gicap.h"
+#include "kernels.h"
+
+namespace gic {
+namespace {
+
+constexpr int kMaxTaps = 32;     // f * s per filter held in registers
+constexpr int kOutDim = 100;     // feature2out width (discriminator.py:28)
+constexpr int kOutPad = 104;
+
+struct ConvMeta {
+  int nconv, F, Fp, s;
+  int fsize[GIC_MAX_CONVS], nfilt[GIC_MAX_CONVS], foff[GIC_MAX_CONVS];
+  const float* w[GIC_MAX_CONVS];
+  const float* b[GIC_MAX_CONVS];
+  float* dw[GIC_MAX_CONVS];
+  float* db[GIC_MAX_CONVS];
+};
+
+__device__ __forceinline__ int conv_of(const ConvMeta& cm, int col) {
+  int k = 0;
+  while (k + 1 < cm.nconv && col >= cm.foff[k + 1]) ++k;
+  return k;
+}
+
+// ---- ids input: emb[(b,l), e] = W_emb[e, id]   (one_hot(real) @ W^T as a gather; training.py:158)
+__global__ void disc_emb_gather_kernel(const float* __restrict__ w, const int64_t* __restrict__ ids, float* __restrict__ emb,
+                                       long rows, int De, int V) {
+  const long total = rows * De;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / De;
+    const int e = (int)(i % De);
+    long id = ids[r];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    emb[i] = w[(long)e * V + id];
+  }
+}
+__global__ void disc_emb_scatter_kernel(const float* __restrict__ demb_f32, const void* __restrict__ demb, int dt,
+                                        const int64_t* __restrict__ ids, float* __restrict__ dw, long rows, int De, int V) {
+  const long total = rows * De;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / De;
+    const int e = (int)(i % De);
+    long id = ids[r];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    atomicAdd(&dw[(long)e * V + id], ld_as_f32(demb, i, dt));
+  }
+}
+
+// ---- fused conv + bias + ReLU + max-over-time.  grid = B*R blocks, 256 threads stride over the F filters.
+template <typename TA>
+__global__ __launch_bounds__(256) void disc_conv_pool_fwd_kernel(const float* __restrict__ emb, ConvMeta cm, int L, int De, int R,
+                                                                   TA* __restrict__ pooled, uint8_t* __restrict__ argmax) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // [L][s]
+  const int br = blockIdx.x, b = br / R, r = br % R, s = cm.s;
+  for (int i = threadIdx.x; i < L * s; i += 256) xs[i] = emb[((long)b * L + i / s) * De + r * s + i % s];
+  __syncthreads();
+  for (int col = threadIdx.x; col < cm.Fp; col += 256) {
+    float best = 0.f;
+    int bt = 0;
+    if (col < cm.F) {
+      const int k = conv_of(cm, col);
+      const int f = cm.fsize[k], ch = col - cm.foff[k], taps = f * s;
+      float w[kMaxTaps];
+#pragma unroll
+      for (int j = 0; j < kMaxTaps; ++j) w[j] = j < taps ? cm.w[k][(long)ch * taps + j] : 0.f;
+      const float bias = cm.b[k][ch];
+      best = -1.f;
+      for (int t = 0; t + f <= L; ++t) {
+        float v = bias;
+#pragma unroll
+        for (int j = 0; j < kMaxTaps; ++j)
+          if (j < taps) v += w[j] * xs[t * s + j];      // window (t..t+f-1) x s is contiguous in xs
+        v = fmaxf(v, 0.f);                              // relu then max (discriminator.py:42,45)
+        if (v > best) { best = v; bt = t; }
+      }
+    }
+    pooled[(long)br * cm.Fp + col] = from_f32<TA>(best);
+    argmax[(long)br * cm.Fp + col] = (uint8_t)bt;
+  }
+}
+
+// ---- conv backward, input side: d emb.  One block per (b, r) owns its s embedding columns.
+template <typename TA>
+__global__ __launch_bounds__(256) void disc_conv_pool_bwd_x_kernel(const float* __restrict__ dpooled, const TA* __restrict__ pooled,
+                                                                     const uint8_t* __restrict__ argmax, ConvMeta cm, int L, int De, int R,
+                                                                     TA* __restrict__ demb) {
+  extern __shared__ __attribute__((aligned(16))) float dx[];   // [L][s]
+  const int br = blockIdx.x, b = br / R, r = br % R, s = cm.s;
+  for (int i = threadIdx.x; i < L * s; i += 256) dx[i] = 0.f;
+  __syncthreads();
+  for (int col = threadIdx.x; col < cm.F; col += 256) {
+    const long o = (long)br * cm.Fp + col;
+    if (to_f32<TA>(pooled[o]) <= 0.f) continue;        // relu gate
+    const float g = dpooled[o];
+    const int k = conv_of(cm, col);
+    const int taps = cm.fsize[k] * s, ch = col - cm.foff[k], t = argmax[o];
+    for (int j = 0; j < taps; ++j) atomicAdd(&dx[t * s + j], g * cm.w[k][(long)ch * taps + j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L * s; i += 256)
+    demb[((long)b * L + i / s) * De + r * s + i % s] = from_f32<TA>(dx[i]);
+}
+
+// ---- conv backward, weight side: block = 64 filters x 4 row lanes, rows split over gridDim.y
+template <typename TA>
+__global__ __launch_bounds__(256) void disc_conv_pool_bwd_w_kernel(const float* __restrict__ dpooled, const TA* __restrict__ pooled,
+                                                                     const uint8_t* __restrict__ argmax, const float* __restrict__ emb,
+                                                                     ConvMeta cm, int L, int De, int R, long rows) {
+  __shared__ float red[4][64][kMaxTaps + 1];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, s = cm.s;
+  const int col = blockIdx.x * 64 + cx;
+  float acc[kMaxTaps + 1];
+#pragma unroll
+  for (int j = 0; j <= kMaxTaps; ++j) acc[j] = 0.f;
+  int k = 0, taps = 0, ch = 0;
+  if (col < cm.F) {
+    k = conv_of(cm, col);
+    taps = cm.fsize[k] * s;
+    ch = col - cm.foff[k];
+    for (long m = (long)blockIdx.y * 4 + ry; m < rows; m += (long)gridDim.y * 4) {
+      const long o = m * cm.Fp + col;
+      if (to_f32<TA>(pooled[o]) <= 0.f) continue;
+      const float g = dpooled[o];
+      const int b = (int)(m / R), r = (int)(m % R), t = argmax[o];
+      const float* x = emb + ((long)b * L + t) * De + r * s;     // tap (j, e) at x[j*De + e]
+#pragma unroll
+      for (int j = 0; j < kMaxTaps; ++j)
+        if (j < taps) acc[j] += g * x[(j / s) * De + (j % s)];
+      acc[kMaxTaps] += g;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j <= kMaxTaps; ++j) red[ry][cx][j] = acc[j];
+  __syncthreads();
+  if (ry == 0 && col < cm.F) {
+    for (int j = 0; j < taps; ++j)
+      atomicAdd(&cm.dw[k][(long)ch * taps + j], red[0][cx][j] + red[1][cx][j] + red[2][cx][j] + red[3][cx][j]);
+    atomicAdd(&cm.db[k][ch], red[0][cx][kMaxTaps] + red[1][cx][kMaxTaps] + red[2][cx][kMaxTaps] + red[3][cx][kMaxTaps]);
+  }
+}
+
+// ---- logits[m] = feat[m,:] . w + b   (out2logits, discriminator.py:60)
+__global__ void disc_out_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ bias,
+                                    float* __restrict__ logits, long rows) {
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= rows) return;
+  float s = bias[0];
+  for (int j = 0; j < kOutDim; ++j) s += feat[m * kOutDim + j] * w[j];
+  logits[m] = s;
+}
+
+// dfeat[m,j] = dlogit[m] * w[j] (pad cols zero); optional dw[j] += sum_m dlogit[m] feat[m,j], db += sum_m dlogit[m]
+template <typename TA>
+__global__ __launch_bounds__(256) void disc_out_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ feat,
+                                                             const float* __restrict__ w, TA* __restrict__ dfeat,
+                                                             float* __restrict__ dw, float* __restrict__ db, long rows) {
+  __shared__ float red[2][128];
+  const int j = threadIdx.x & 127, half = threadIdx.x >> 7;
+  float aw = 0.f, ab = 0.f;
+  const float wj = j < kOutDim ? w[j] : 0.f;
+  for (long m = (long)blockIdx.x * 2 + half; m < rows; m += (long)gridDim.x * 2) {
+    const float g = dlogits[m];
+    if (j < kOutPad) dfeat[m * kOutPad + j] = from_f32<TA>(g * wj);
+    if (dw && j < kOutDim) aw += g * feat[m * kOutDim + j];
+    if (j == 0) ab += g;
+  }
+  if (!dw) return;
+  red[half][j] = aw;
+  __syncthreads();
+  if (half == 0 && j < kOutDim) atomicAdd(&dw[j], red[0][j] + red[1][j]);
+  __syncthreads();
+  red[half][j] = ab;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(db, red[0][0] + red[1][0]);
+}
+
+// ---- highway backward pointwise (discriminator.py:53-58 differentiated):
+//   dy = dydrop * keep * scale;  dh = dy * (sg(1-sg)(relu(h)-x) + sg*[h>0]);  dx_direct = dy * (1-sg)
+template <typename TA>
+__global__ void disc_highway_bwd_kernel(const float* __restrict__ dydrop, const uint8_t* __restrict__ keep, float scale,
+                                        const float* __restrict__ hpre, const TA* __restrict__ pooled, TA* __restrict__ dh,
+                                        float* __restrict__ dpooled, long rows, int F, int Fp) {
+  const long total = rows * Fp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % Fp);
+    float vdh = 0.f, vdx = 0.f;
+    if (n < F) {
+      float dy = dydrop[i] * scale;
+      if (keep) dy *= (float)keep[i];
+      const float h = hpre[i], x = to_f32<TA>(pooled[i]);
+      const float sg = 1.f / (1.f + expf(-h));
+      vdh = dy * (sg * (1.f - sg) * (fmaxf(h, 0.f) - x) + (h > 0.f ? sg : 0.f));
+      vdx = dy * (1.f - sg);
+    }
+    dh[i] = from_f32<TA>(vdh);
+    dpooled[i] = vdx;
+  }
+}
+
+struct DCtx {
+  int B, L, V, De, R, s, F, Fp, dt;
+  long rowsBL, rowsBR;
+  ConvMeta cm;
+};
+
+int make_ctx(const gic_disc_dims* d, const gic_disc_params* P, const gic_disc_grads* G, DCtx& c) {
+  GIC_CHECK_ARG(d, "disc: null dims");
+  GIC_CHECK_ARG(d->B > 0 && d->L > 0 && d->V > 0 && d->De > 0 && d->R > 0, "disc: bad dims");
+  GIC_CHECK_ARG(d->De % d->R == 0, "disc: disc_embed_dim %d not divisible by disc_num_rep %d", d->De, d->R);
+  GIC_CHECK_ARG(d->nconv >= 1 && d->nconv <= GIC_MAX_CONVS, "disc: nconv must be 1..%d", GIC_MAX_CONVS);
+  GIC_CHECK_ARG(d->dtype == DT_F32 || d->dtype == DT_BF16, "disc: bad dtype");
+  c.B = d->B; c.L = d->L; c.V = d->V; c.De = d->De; c.R = d->R; c.s = d->De / d->R; c.dt = d->dtype;
+  c.F = d->F; c.Fp = d->Fp;
+  c.rowsBL = (long)d->B * d->L; c.rowsBR = (long)d->B * d->R;
+  GIC_CHECK_ARG(c.Fp >= c.F && c.Fp % 8 == 0, "disc: Fp=%d must be >= F=%d and a multiple of 8", c.Fp, c.F);
+  GIC_CHECK_ARG(c.L <= 255, "disc: L=%d exceeds the uint8 argmax range", c.L);
+  ConvMeta& cm = c.cm;
+  cm.nconv = d->nconv; cm.F = c.F; cm.Fp = c.Fp; cm.s = c.s;
+  int off = 0;
+  for (int k = 0; k < d->nconv; ++k) {
+    GIC_CHECK_ARG(d->fsize[k] >= 1 && d->fsize[k] <= d->L, "disc: filter size %d does not fit caption length %d", d->fsize[k], d->L);
+    GIC_CHECK_ARG(d->fsize[k] * c.s <= kMaxTaps, "disc: filter taps f*s=%d exceed %d", d->fsize[k] * c.s, kMaxTaps);
+    cm.fsize[k] = d->fsize[k]; cm.nfilt[k] = d->nfilt[k]; cm.foff[k] = off; off += d->nfilt[k];
+    cm.w[k] = P ? P->conv_w[k] : nullptr; cm.b[k] = P ? P->conv_b[k] : nullptr;
+    cm.dw[k] = G ? G->conv_w[k] : nullptr; cm.db[k] = G ? G->conv_b[k] : nullptr;
+    GIC_CHECK_ARG(!P || (cm.w[k] && cm.b[k]), "disc: null conv %d parameter", k);
+  }
+  GIC_CHECK_ARG(off == c.F, "disc: F=%d != sum(nfilt)=%d", c.F, off);
+  return GIC_OK;
+}
+
+inline int grid1d(long total, int cap = 2048) {
+  long g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+template <typename TA>
+int disc_fwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S, const gic_disc_state* st,
+               const void* inp_soft, long ld_inp, const int64_t* inp_ids, int train, const uint8_t* keep_mask,
+               uint64_t seed, float* logits, hipStream_t stream) {
+  // 1. embedding
+  if (inp_ids) {
+    hipLaunchKernelGGL(disc_emb_gather_kernel, dim3(grid1d(c.rowsBL * c.De)), dim3(256), 0, stream, P->emb, inp_ids, st->emb,
+                       c.rowsBL, c.De, c.V);
+    GIC_CHECK_LAUNCH("disc_emb_gather");
+  } else {
+    GemmDesc g;
+    g.A = inp_soft; g.lda = ld_inp; g.B = S->emb; g.ldb = c.V; g.C = st->emb; g.ldc = c.De;
+    g.M = (int)c.rowsBL; g.N = c.De; g.K = c.V; g.in_dtype = c.dt; g.out_dtype = DT_F32;
+    GIC_PROPAGATE(gemm(g, stream));
+  }
+  // 2. conv + relu + max over time
+  hipLaunchKernelGGL((disc_conv_pool_fwd_kernel<TA>), dim3((unsigned)c.rowsBR), dim3(256), c.L * c.s * sizeof(float), stream,
+                     (const float*)st->emb, c.cm, c.L, c.De, c.R, (TA*)st->pooled, st->argmax);
+  GIC_CHECK_LAUNCH("disc_conv_pool_fwd");
+  // 3. highway + dropout (fused epilogue)
+  {
+    GemmDesc g;
+    g.A = st->pooled; g.lda = c.Fp; g.B = S->hw_w; g.ldb = c.Fp; g.C = st->ydrop; g.ldc = c.Fp;
+    g.M = (int)c.rowsBR; g.N = c.F; g.K = c.Fp; g.in_dtype = c.dt; g.out_dtype = c.dt; g.bias = P->hw_b;
+    g.epi = EPI_HIGHWAY; g.X = st->pooled; g.ldx = c.Fp; g.Hpre = st->hpre; g.ldh = c.Fp;
+    if (train) {
+      g.keep_scale = 1.f / (1.f - 0.2f);     // nn.Dropout(0.2), discriminator.py:10,30
+      g.drop_p = 0.2f;
+      if (keep_mask) { g.mask = keep_mask; g.ldmask = c.F; } else { g.use_philox = 1; g.seed = seed; g.stream = 0x44495343ull; }
+      g.mask_out = st->keep; g.ldmask_out = c.Fp;
+    }
+    GIC_PROPAGATE(gemm(g, stream));
+  }
+  // 4. feature2out, out2logits
+  {
+    GemmDesc g;
+    g.A = st->ydrop; g.lda = c.Fp; g.B = S->f2o_w; g.ldb = c.Fp; g.C = st->feat; g.ldc = kOutDim;
+    g.M = (int)c.rowsBR; g.N = kOutDim; g.K = c.Fp; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.bias = P->f2o_b;
+    GIC_PROPAGATE(gemm(g, stream));
+  }
+  hipLaunchKernelGGL(disc_out_fwd_kernel, dim3(cdiv(c.rowsBR, 256)), dim3(256), 0, stream, (const float*)st->feat, P->o2l_w, P->o2l_b,
+                     logits, c.rowsBR);
+  GIC_CHECK_LAUNCH("disc_out_fwd");
+  return GIC_OK;
+}
+
+template <typename TA>
+int disc_bwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S, const gic_disc_state* st,
+               const gic_disc_bwd_ws* ws, const void* inp_soft, long ld_inp, const int64_t* inp_ids, int train,
+               const float* d_logits, const gic_disc_grads* G, int accumulate, void* d_inp, long ld_dinp, hipStream_t stream) {
+  const long MR = c.rowsBR;
+  if (G && !accumulate) {   // atomically-accumulated small grads start from zero
+    GIC_PROPAGATE(fill_zero(G->o2l_w, kOutDim * sizeof(float), stream));
+    GIC_PROPAGATE(fill_zero(G->o2l_b, sizeof(float), stream));
+    for (int k = 0; k < c.cm.nconv; ++k) {
+      GIC_PROPAGATE(fill_zero(G->conv_w[k], (size_t)c.cm.nfilt[k] * c.cm.fsize[k] * c.s * sizeof(float), stream));
+      GIC_PROPAGATE(fill_zero(G->conv_b[k], (size_t)c.cm.nfilt[k] * sizeof(float), stream));
+    }
+    if (inp_ids) GIC_PROPAGATE(fill_zero(G->emb, (size_t)c.De * c.V * sizeof(float), stream));
+  }
+  // 1. out2logits backward
+  hipLaunchKernelGGL((disc_out_bwd_kernel<TA>), dim3(256), dim3(256), 0, stream, d_logits, (const float*)st->feat, P->o2l_w,
+                     (TA*)ws->dfeat, G ? G->o2l_w : nullptr, G ? G->o2l_b : nullptr, MR);
+  GIC_CHECK_LAUNCH("disc_out_bwd");
+  // 2. feature2out backward
+  {
+    GemmDesc g;   // dydrop[MR, Fp] = dfeat[MR,104] f2o_w[104, Fp]
+    g.A = ws->dfeat; g.lda = kOutPad; g.a_kc = 1; g.B = S->f2o_w; g.ldb = c.Fp; g.b_kc = 0; g.C = ws->dydrop; g.ldc = c.Fp;
+    g.M = (int)MR; g.N = c.Fp; g.K = kOutPad; g.in_dtype = c.dt; g.out_dtype = DT_F32;
+    GIC_PROPAGATE(gemm(g, stream));
+    if (G) {
+      GemmDesc w;   // dW_f2o[100, F] = dfeat^T ydrop
+      w.A = ws->dfeat; w.lda = kOutPad; w.a_kc = 0; w.B = st->ydrop; w.ldb = c.Fp; w.b_kc = 0; w.C = G->f2o_w; w.ldc = c.F;
+      w.M = kOutDim; w.N = c.F; w.K = (int)MR; w.in_dtype = c.dt; w.out_dtype = DT_F32; w.accumulate = accumulate;
+      GIC_PROPAGATE(gemm(w, stream));
+      GIC_PROPAGATE(colsum(ws->dfeat, c.dt, kOutPad, MR, kOutDim, G->f2o_b, nullptr, accumulate, stream));
+    }
+  }
+  // 3. highway backward
+  hipLaunchKernelGGL((disc_highway_bwd_kernel<TA>), dim3(grid1d(MR * c.Fp)), dim3(256), 0, stream, (const float*)ws->dydrop,
+                     train ? (const uint8_t*)st->keep : nullptr, train ? 1.f / (1.f - 0.2f) : 1.f, (const float*)st->hpre,
+                     (const TA*)st->pooled, (TA*)ws->dh, ws->dpooled, MR, c.F, c.Fp);
+  GIC_CHECK_LAUNCH("disc_highway_bwd");
+  {
+    GemmDesc g;   // dpooled += dh hw_w
+    g.A = ws->dh; g.lda = c.Fp; g.a_kc = 1; g.B = S->hw_w; g.ldb = c.Fp; g.b_kc = 0; g.C = ws->dpooled; g.ldc = c.Fp;
+    g.M = (int)MR; g.N = c.Fp; g.K = c.Fp; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.accumulate = 1;
+    GIC_PROPAGATE(gemm(g, stream));
+    if (G) {
+      GemmDesc w;   // dW_hw[F,F] = dh^T pooled
+      w.A = ws->dh; w.lda = c.Fp; w.a_kc = 0; w.B = st->pooled; w.ldb = c.Fp; w.b_kc = 0; w.C = G->hw_w; w.ldc = c.F;
+      w.M = c.F; w.N = c.F; w.K = (int)MR; w.in_dtype = c.dt; w.out_dtype = DT_F32; w.accumulate = accumulate;
+      GIC_PROPAGATE(gemm(w, stream));
+      GIC_PROPAGATE(colsum(ws->dh, c.dt, c.Fp, MR, c.F, G->hw_b, nullptr, accumulate, stream));
+    }
+  }
+  // 4. conv / pool backward
+  if (G) {
+    int gy = cdiv(MR, 4 * 8);
+    gy = gy > 64 ? 64 : gy;
+    hipLaunchKernelGGL((disc_conv_pool_bwd_w_kernel<TA>), dim3(cdiv(c.F, 64), gy), dim3(256), 0, stream, (const float*)ws->dpooled,
+                       (const TA*)st->pooled, (const uint8_t*)st->argmax, (const float*)st->emb, c.cm, c.L, c.De, c.R, MR);
+    GIC_CHECK_LAUNCH("disc_conv_pool_bwd_w");
+  }
+  hipLaunchKernelGGL((disc_conv_pool_bwd_x_kernel<TA>), dim3((unsigned)MR), dim3(256), c.L * c.s * sizeof(float), stream,
+                     (const float*)ws->dpooled, (const TA*)st->pooled, (const uint8_t*)st->argmax, c.cm, c.L, c.De, c.R, (TA*)ws->demb);
+  GIC_CHECK_LAUNCH("disc_conv_pool_bwd_x");
+  // 5. embedding backward
+  if (G) {
+    if (inp_ids) {
+      hipLaunchKernelGGL(disc_emb_scatter_kernel, dim3(grid1d(c.rowsBL * c.De)), dim3(256), 0, stream, (const float*)nullptr,
+                         (const void*)ws->demb, c.dt, inp_ids, G->emb, c.rowsBL, c.De, c.V);
+      GIC_CHECK_LAUNCH("disc_emb_scatter");
+    } else {
+      GemmDesc w;   // dW_emb[De, V] = demb^T inp
+      w.A = ws->demb; w.lda = c.De; w.a_kc = 0; w.B = inp_soft; w.ldb = ld_inp; w.b_kc = 0; w.C = G->emb; w.ldc = c.V;
+      w.M = c.De; w.N = c.V; w.K = (int)c.rowsBL; w.in_dtype = c.dt; w.out_dtype = DT_F32; w.accumulate = accumulate;
+      GIC_PROPAGATE(gemm(w, stream));
+    }
+  }
+  if (d_inp) {
+    GemmDesc g;   // d_inp[B*L, V] = demb[B*L, De] W_emb[De, V]
+    g.A = ws->demb; g.lda = c.De; g.a_kc = 1; g.B = S->emb; g.ldb = c.V; g.b_kc = 0; g.C = d_inp; g.ldc = ld_dinp;
+    g.M = (int)c.rowsBL; g.N = c.V; g.K = c.De; g.in_dtype = c.dt; g.out_dtype = c.dt;
+    GIC_PROPAGATE(gemm(g, stream));
+  }
+  return GIC_OK;
+}
+
+}  // namespace
+}  // namespace gic
+
+using namespace gic;
+
+extern "C" {
+
+// shadow.emb [De,V]; shadow.hw_w [Fp,Fp] and shadow.f2o_w [104,Fp] zero-padded images of highway / feature2out
+int gic_disc_prepare(const gic_disc_dims* dims, const gic_disc_params* P, const gic_disc_shadow* S, void* stream_) {
+  DCtx c;
+  GIC_PROPAGATE(make_ctx(dims, P, nullptr, c));
+  GIC_CHECK_ARG(P && S && P->emb && P->hw_w && P->f2o_w && S->emb && S->hw_w && S->f2o_w, "disc_prepare: null pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  if ((const void*)S->emb != (const void*)P->emb)
+    GIC_PROPAGATE(cast2d(P->emb, DT_F32, c.V, S->emb, c.dt, c.V, c.De, c.V, stream));
+  const size_t a = dtype_size(c.dt);
+  GIC_PROPAGATE(fill_zero(S->hw_w, (size_t)c.Fp * c.Fp * a, stream));
+  GIC_PROPAGATE(cast2d(P->hw_w, DT_F32, c.F, S->hw_w, c.dt, c.Fp, c.F, c.F, stream));
+  GIC_PROPAGATE(fill_zero(S->f2o_w, (size_t)kOutPad * c.Fp * a, stream));
+  GIC_PROPAGATE(cast2d(P->f2o_w, DT_F32, c.F, S->f2o_w, c.dt, c.Fp, kOutDim, c.F, stream));
+  return GIC_OK;
+}
+
+int gic_disc_fwd(const gic_disc_dims* dims, const gic_disc_params* P, const gic_disc_shadow* S, const gic_disc_state* st,
+                 const void* inp_soft, int64_t ld_inp, const int64_t* inp_ids, int train, const uint8_t* keep_mask,
+                 uint64_t seed, float* logits, void* stream) {
+  DCtx c;
+  GIC_PROPAGATE(make_ctx(dims, P, nullptr, c));
+  GIC_CHECK_ARG(P && S && st && logits, "disc_fwd: null argument");
+  GIC_CHECK_ARG((inp_soft != nullptr) != (inp_ids != nullptr), "disc_fwd: pass exactly one of inp_soft / inp_ids");
+  GIC_CHECK_ARG(!inp_soft || ld_inp >= c.V, "disc_fwd: ld_inp < V");
+  GIC_CHECK_ARG(st->emb && st->pooled && st->argmax && st->hpre && st->ydrop && st->feat && (!train || st->keep), "disc_fwd: null state buffer");
+  GIC_CHECK_ARG(P->emb && P->hw_b && P->f2o_b && P->o2l_w && P->o2l_b && S->emb && S->hw_w && S->f2o_w, "disc_fwd: null parameter");
+  if (c.dt == DT_F32)
+    return disc_fwd_t<float>(c, P, S, st, inp_soft, ld_inp, inp_ids, train, keep_mask, seed, logits, (hipStream_t)stream);
+  return disc_fwd_t<bf16_t>(c, P, S, st, inp_soft, ld_inp, inp_ids, train, keep_mask, seed, logits, (hipStream_t)stream);
+}
+
+int gic_disc_bwd(const gic_disc_dims* dims, const gic_disc_params* P, const gic_disc_shadow* S, const gic_disc_state* st,
+                 const gic_disc_bwd_ws* ws, const void* inp_soft, int64_t ld_inp, const int64_t* inp_ids, int train,
+                 const float* d_logits, const gic_disc_grads* G, int accumulate, void* d_inp, int64_t ld_dinp, void* stream) {
+  DCtx c;
+  GIC_PROPAGATE(make_ctx(dims, P, G, c));
+  GIC_CHECK_ARG(P && S && st && ws && d_logits, "disc_bwd: null argument");
+  GIC_CHECK_ARG((inp_soft != nullptr) != (inp_ids != nullptr), "disc_bwd: pass exactly one of inp_soft / inp_ids");
+  GIC_CHECK_ARG(ws->dfeat && ws->dh && ws->dydrop && ws->dpooled && ws->demb, "disc_bwd: null workspace buffer");
+  GIC_CHECK_ARG(!d_inp || (inp_soft && ld_dinp >= c.V), "disc_bwd: d_inp needs a soft input and ld_dinp >= V");
+  if (G) {
+    GIC_CHECK_ARG(G->emb && G->hw_w && G->hw_b && G->f2o_w && G->f2o_b && G->o2l_w && G->o2l_b, "disc_bwd: null grad buffer");
+    for (int k = 0; k < c.cm.nconv; ++k) GIC_CHECK_ARG(G->conv_w[k] && G->conv_b[k], "disc_bwd: null conv %d grad buffer", k);
+  }
+  if (c.dt == DT_F32)
+    return disc_bwd_t<float>(c, P, S, st, ws, inp_soft, ld_inp, inp_ids, train, d_logits, G, accumulate, d_inp, ld_dinp, (hipStream_t)stream);
+  return disc_bwd_t<bf16_t>(c, P, S, st, ws, inp_soft, ld_inp, inp_ids, train, d_logits, G, accumulate, d_inp, ld_dinp, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// Host-side descriptor of the one MFMA GEMM family every dense contraction of
+// the hot path goes through (kernels in gemm.hip).
+//
+//   C[m,n] = epi( alpha * sum_k A(m,k) * B(n,k) )
+//
+// A(m,k) = a_kc ? A[m*lda + k] : A[k*lda + m]      (k-contiguous / m-contiguous)
+// B(n,k) = b_kc ? B[n*ldb + k] : B[k*ldb + n]
+// so  forward  y = x W^T      : a_kc=1, b_kc=1   ("NT")
+//     dgrad    dx = dy W      : a_kc=1, b_kc=0   ("NN")
+//     wgrad    dW = dy^T x    : a_kc=0, b_kc=0   ("TN")
+#pragma once
+#include "common.h"
+
+namespace gic {
+
+enum GemmEpi { EPI_PLAIN = 0, EPI_HIGHWAY = 1 };
+
+struct GemmDesc {
+  const void* A = nullptr;
+  const void* B = nullptr;
+  void* C = nullptr;
+  int M = 0, N = 0, K = 0;
+  long lda = 0, ldb = 0, ldc = 0;
+  int a_kc = 1, b_kc = 1;
+  int in_dtype = DT_F32, out_dtype = DT_F32;
+  const float* bias = nullptr;   // per output column n (optional)
+  int accumulate = 0;            // C += result
+  float alpha = 1.f;
+  int epi = EPI_PLAIN;
+  // ---- EPI_HIGHWAY (discriminator.py:53-58): h = acc+bias; y = sig(h)*relu(h) + (1-sig(h))*x; C = y*keep*keep_scale
+  const void* X = nullptr; long ldx = 0;        // carry input, in_dtype
+  float* Hpre = nullptr; long ldh = 0;          // pre-activation h (saved for backward)
+  const uint8_t* mask = nullptr; long ldmask = 0;   // explicit keep mask (0/1) or null
+  uint8_t* mask_out = nullptr; long ldmask_out = 0;   // keep mask actually used, written for backward (optional)
+  float keep_scale = 1.f;                       // 1/(1-p) in train mode, 1 in eval
+  int use_philox = 0; float drop_p = 0.f; uint64_t seed = 0, stream = 0;
+};
+
+// Enqueue on `stream`. Returns GIC_OK or a negative Status (message via gic_last_error()).
+int gemm(const GemmDesc& d, hipStream_t stream);
+
+}  // namespace gic

@@ -1,0 +1,345 @@
+// MFMA GEMM family for gfx950 (MI355X).  One templated kernel covers every dense
+// contraction on the hot path (LSTM gates, vocab projection, discriminator
+// embedding / highway / head, all dgrad and wgrad products):
+//
+//  * 16x16 MFMA tiles: v_mfma_f32_16x16x32_bf16 (bf16 in, f32 acc) or
+//    v_mfma_f32_16x16x4_f32 (exact f32 fma chain; parity mode).
+//  * 256 threads = 4 waves (2x2), block tile 128x128 or 64x64, 128 bytes of K per
+//    LDS row (+16 B pad so a 16-lane ds_read_b128 group hits 64 distinct banks).
+//  * operands may be k-contiguous (LDS image [row][k], ds_read_b128 fragments) or
+//    m/n-contiguous (LDS image [k][row]; bf16 fragments come out of
+//    ds_read_b64_tr_b16, the gfx950 transposing LDS read) so dgrad / wgrad need
+//    no transposed copies in HBM.
+//  * global -> VGPR -> LDS staging with the next tile's loads in flight under the
+//    current tile's MFMAs; 16-byte loads/stores when shapes allow, scalar fallback
+//    otherwise (odd test shapes).
+//  * XCD-aware block -> tile map: each of the 8 XCDs owns a contiguous run of
+//    tiles that share B (weight) panels in its private L2.
+#include "gemm.h"
+
+namespace gic {
+
+namespace {
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+template <typename TI, typename TO, bool AKC, bool BKC, int BM, int BN, bool VEC, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d) {
+  constexpr int SZ = sizeof(TI);
+  constexpr int BK = 128 / SZ;          // K elements per tile
+  constexpr int VE = 16 / SZ;           // elements per 16-byte chunk
+  constexpr int SA = AKC ? 144 : BM * SZ + 16;   // LDS row stride (bytes)
+  constexpr int SB = BKC ? 144 : BN * SZ + 16;
+  constexpr int A_BYTES = AKC ? BM * SA : BK * SA;
+  constexpr int B_BYTES = BKC ? BN * SB : BK * SB;
+  constexpr int TM = BM / 32, TN = BN / 32;      // 16x16 tiles per wave
+  constexpr int CA = BM / 32, CB = BN / 32;      // 16-B chunks per thread per tile
+  constexpr bool IS_BF16 = (SZ == 2);
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  // ---- XCD-aware tile assignment (bijective remap; blocks b and b+8 share an XCD)
+  const int tiles_m = (d.M + BM - 1) / BM;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int bm0 = (bid % tiles_m) * BM;
+  const int bn0 = (bid / tiles_m) * BN;
+
+  const TI* __restrict__ A = (const TI*)d.A;
+  const TI* __restrict__ B = (const TI*)d.B;
+  const int M = d.M, N = d.N, K = d.K;
+  const long lda = d.lda, ldb = d.ldb;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[CA], rb[CB];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  auto gload = [&](int kt) {
+    if constexpr (VEC) {
+      const int k0 = kt * BK;
+#pragma unroll
+      for (int i = 0; i < CA; ++i) {
+        const int c = tid + i * 256;
+        if constexpr (AKC) {
+          const int row = c >> 3, kc = c & 7;
+          const int m = bm0 + row, k = k0 + kc * VE;
+          ra[i] = (m < M && k < K) ? *(const uint4*)(A + (long)m * lda + k) : zero4;
+        } else {
+          constexpr int CPR = BM / VE;
+          const int krow = c / CPR, mc = c % CPR;
+          const int k = k0 + krow, m = bm0 + mc * VE;
+          ra[i] = (k < K && m < M) ? *(const uint4*)(A + (long)k * lda + m) : zero4;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < CB; ++i) {
+        const int c = tid + i * 256;
+        if constexpr (BKC) {
+          const int row = c >> 3, kc = c & 7;
+          const int n = bn0 + row, k = k0 + kc * VE;
+          rb[i] = (n < N && k < K) ? *(const uint4*)(B + (long)n * ldb + k) : zero4;
+        } else {
+          constexpr int CPR = BN / VE;
+          const int krow = c / CPR, nc = c % CPR;
+          const int k = k0 + krow, n = bn0 + nc * VE;
+          rb[i] = (k < K && n < N) ? *(const uint4*)(B + (long)k * ldb + n) : zero4;
+        }
+      }
+    }
+  };
+
+  auto sstore = [&](int kt) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int i = 0; i < CA; ++i) {
+        const int c = tid + i * 256;
+        if constexpr (AKC) {
+          *(uint4*)(sA + (c >> 3) * SA + (c & 7) * 16) = ra[i];
+        } else {
+          constexpr int CPR = BM / VE;
+          *(uint4*)(sA + (c / CPR) * SA + (c % CPR) * 16) = ra[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < CB; ++i) {
+        const int c = tid + i * 256;
+        if constexpr (BKC) {
+          *(uint4*)(sB + (c >> 3) * SB + (c & 7) * 16) = rb[i];
+        } else {
+          constexpr int CPR = BN / VE;
+          *(uint4*)(sB + (c / CPR) * SB + (c % CPR) * 16) = rb[i];
+        }
+      }
+    } else {
+      // scalar fallback: element-wise guarded copy (odd shapes / unaligned leading dims)
+      const int k0 = kt * BK;
+      for (int e = tid; e < BM * BK; e += 256) {
+        if constexpr (AKC) {
+          const int row = e / BK, kk = e % BK;
+          const int m = bm0 + row, k = k0 + kk;
+          *(TI*)(sA + row * SA + kk * SZ) = (m < M && k < K) ? A[(long)m * lda + k] : (TI)0.f;
+        } else {
+          const int kk = e / BM, row = e % BM;
+          const int m = bm0 + row, k = k0 + kk;
+          *(TI*)(sA + kk * SA + row * SZ) = (m < M && k < K) ? A[(long)k * lda + m] : (TI)0.f;
+        }
+      }
+      for (int e = tid; e < BN * BK; e += 256) {
+        if constexpr (BKC) {
+          const int row = e / BK, kk = e % BK;
+          const int n = bn0 + row, k = k0 + kk;
+          *(TI*)(sB + row * SB + kk * SZ) = (n < N && k < K) ? B[(long)n * ldb + k] : (TI)0.f;
+        } else {
+          const int kk = e / BN, row = e % BN;
+          const int n = bn0 + row, k = k0 + kk;
+          *(TI*)(sB + kk * SB + row * SZ) = (n < N && k < K) ? B[(long)k * ldb + n] : (TI)0.f;
+        }
+      }
+    }
+  };
+
+  auto compute = [&]() {
+    if constexpr (IS_BF16) {
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          const int r0 = wr * (BM / 2) + t * 16;
+          if constexpr (AKC) {
+            fa[t] = *(const bf16x8*)(sA + (r0 + lr) * SA + ks * 64 + lg * 16);
+          } else {
+            // [k][m] image: lane (q=lr>>2, p=lr&3) addresses row k0+q, cols 4p..4p+3; receives column lr
+            const unsigned char* p0 = sA + (ks * 32 + lg * 8 + (lr >> 2)) * SA + (r0 + 4 * (lr & 3)) * 2;
+            bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
+            bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * SA));
+            fa[t] = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+          const int r0 = wc * (BN / 2) + t * 16;
+          if constexpr (BKC) {
+            fb[t] = *(const bf16x8*)(sB + (r0 + lr) * SB + ks * 64 + lg * 16);
+          } else {
+            const unsigned char* p0 = sB + (ks * 32 + lg * 8 + (lr >> 2)) * SB + (r0 + 4 * (lr & 3)) * 2;
+            bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
+            bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * SB));
+            fb[t] = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // f32: lane group lg owns k = 8*lg .. 8*lg+7 of the 32-wide tile; MFMA step s
+      // contracts k in {8g+s : g=0..3} (same map for A and B, so the sum covers all 32).
+      float fa[TM][8], fb[TN][8];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int r0 = wr * (BM / 2) + t * 16;
+        if constexpr (AKC) {
+          const float4 v0 = *(const float4*)(sA + (r0 + lr) * SA + lg * 32);
+          const float4 v1 = *(const float4*)(sA + (r0 + lr) * SA + lg * 32 + 16);
+          fa[t][0] = v0.x; fa[t][1] = v0.y; fa[t][2] = v0.z; fa[t][3] = v0.w;
+          fa[t][4] = v1.x; fa[t][5] = v1.y; fa[t][6] = v1.z; fa[t][7] = v1.w;
+        } else {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) fa[t][s] = *(const float*)(sA + (lg * 8 + s) * SA + (r0 + lr) * 4);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const int r0 = wc * (BN / 2) + t * 16;
+        if constexpr (BKC) {
+          const float4 v0 = *(const float4*)(sB + (r0 + lr) * SB + lg * 32);
+          const float4 v1 = *(const float4*)(sB + (r0 + lr) * SB + lg * 32 + 16);
+          fb[t][0] = v0.x; fb[t][1] = v0.y; fb[t][2] = v0.z; fb[t][3] = v0.w;
+          fb[t][4] = v1.x; fb[t][5] = v1.y; fb[t][6] = v1.z; fb[t][7] = v1.w;
+        } else {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) fb[t][s] = *(const float*)(sB + (lg * 8 + s) * SB + (r0 + lr) * 4);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    sstore(kt);
+    __syncthreads();
+    if (kt + 1 < nk) gload(kt + 1);     // next tile's HBM/L2 loads fly under this tile's MFMAs
+    compute();
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D map: col = lane&15, row = (lane>>4)*4 + reg
+  TO* __restrict__ C = (TO*)d.C;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = bn0 + wc * (BN / 2) + j * 16 + lr;
+      if (n >= N) continue;
+      const float bias = d.bias ? d.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = bm0 + wr * (BM / 2) + i * 16 + lg * 4 + r;
+        if (m >= M) continue;
+        float v = d.alpha * acc[i][j][r] + bias;
+        if constexpr (EPI == EPI_PLAIN) {
+          const long o = (long)m * d.ldc + n;
+          if (d.accumulate) v += to_f32<TO>(C[o]);
+          C[o] = from_f32<TO>(v);
+        } else {   // EPI_HIGHWAY
+          const float x = to_f32<TI>(((const TI*)d.X)[(long)m * d.ldx + n]);
+          const float sg = 1.f / (1.f + expf(-v));
+          const float y = sg * fmaxf(v, 0.f) + (1.f - sg) * x;
+          d.Hpre[(long)m * d.ldh + n] = v;
+          float keep = 1.f;
+          if (d.mask) {
+            keep = (float)d.mask[(long)m * d.ldmask + n];
+          } else if (d.use_philox) {
+            uint32_t rnd[4];
+            const uint64_t idx = (uint64_t)m * (uint64_t)N + (uint64_t)n;
+            Philox::gen(d.seed, d.stream, idx >> 2, rnd);
+            keep = Philox::u01(rnd[idx & 3]) >= d.drop_p ? 1.f : 0.f;
+          }
+          if (d.mask_out) d.mask_out[(long)m * d.ldmask_out + n] = (uint8_t)keep;
+          C[(long)m * d.ldc + n] = from_f32<TO>(y * keep * d.keep_scale);
+        }
+      }
+    }
+  }
+}
+
+template <typename TI, typename TO, bool AKC, bool BKC, int BM, int BN, bool VEC, int EPI>
+int launch(const GemmDesc& d, hipStream_t stream) {
+  const int tiles = cdiv(d.M, BM) * cdiv(d.N, BN);
+  hipLaunchKernelGGL((gemm_kernel<TI, TO, AKC, BKC, BM, BN, VEC, EPI>), dim3(tiles), dim3(256), 0, stream, d);
+  GIC_CHECK_LAUNCH("gemm");
+  return GIC_OK;
+}
+
+template <typename TI, typename TO, bool AKC, bool BKC, int EPI>
+int pick_tile(const GemmDesc& d, bool vec, hipStream_t stream) {
+  // 128x128 tiles when they still give >= ~1 block per CU, else 64x64.
+  const long big_tiles = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
+  const bool big = big_tiles >= 192 && d.M >= 128 && d.N >= 128;
+  if (big) {
+    return vec ? launch<TI, TO, AKC, BKC, 128, 128, true, EPI>(d, stream)
+               : launch<TI, TO, AKC, BKC, 128, 128, false, EPI>(d, stream);
+  }
+  return vec ? launch<TI, TO, AKC, BKC, 64, 64, true, EPI>(d, stream)
+             : launch<TI, TO, AKC, BKC, 64, 64, false, EPI>(d, stream);
+}
+
+template <typename TI, typename TO, int EPI>
+int pick_layout(const GemmDesc& d, bool vec, hipStream_t stream) {
+  if (d.a_kc && d.b_kc) return pick_tile<TI, TO, true, true, EPI>(d, vec, stream);
+  if constexpr (EPI == EPI_PLAIN) {
+    if (d.a_kc && !d.b_kc) return pick_tile<TI, TO, true, false, EPI>(d, vec, stream);
+    if (!d.a_kc && !d.b_kc) return pick_tile<TI, TO, false, false, EPI>(d, vec, stream);
+  }
+  set_last_error("gemm: unsupported layout a_kc=%d b_kc=%d epi=%d", d.a_kc, d.b_kc, d.epi);
+  return GIC_ERR_UNSUPPORTED;
+}
+
+template <typename TI, typename TO>
+int pick_epi(const GemmDesc& d, bool vec, hipStream_t stream) {
+  if (d.epi == EPI_PLAIN) return pick_layout<TI, TO, EPI_PLAIN>(d, vec, stream);
+  if (d.epi == EPI_HIGHWAY) return pick_layout<TI, TO, EPI_HIGHWAY>(d, vec, stream);
+  set_last_error("gemm: unknown epilogue %d", d.epi);
+  return GIC_ERR_UNSUPPORTED;
+}
+
+bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+int gemm(const GemmDesc& d, hipStream_t stream) {
+  GIC_CHECK_ARG(d.A && d.B && d.C, "gemm: null operand");
+  GIC_CHECK_ARG(d.M >= 0 && d.N >= 0 && d.K >= 0, "gemm: negative dim");
+  if (d.M == 0 || d.N == 0) return GIC_OK;
+  if (d.epi == EPI_HIGHWAY) GIC_CHECK_ARG(d.X && d.Hpre, "gemm: highway epilogue needs X and Hpre");
+  const int sz = dtype_size(d.in_dtype);
+  const int ve = 16 / sz;
+  bool vec = aligned16(d.A) && aligned16(d.B) && (d.lda % ve == 0) && (d.ldb % ve == 0);
+  // k-contiguous operands: K must be a whole number of 16-B chunks (callers zero-pad K).  m/n-contiguous
+  // operands: a tail chunk reads into the row's padding (ld % ve == 0 >= M) and only feeds rows that are
+  // never stored, so no condition on M / N.
+  if (d.a_kc || d.b_kc) vec = vec && (d.K % ve == 0);
+  if (d.in_dtype == DT_F32 && d.out_dtype == DT_F32) return pick_epi<float, float>(d, vec, stream);
+  if (d.in_dtype == DT_BF16 && d.out_dtype == DT_F32) return pick_epi<bf16_t, float>(d, vec, stream);
+  if (d.in_dtype == DT_BF16 && d.out_dtype == DT_BF16) return pick_epi<bf16_t, bf16_t>(d, vec, stream);
+  set_last_error("gemm: unsupported dtypes in=%d out=%d", d.in_dtype, d.out_dtype);
+  return GIC_ERR_UNSUPPORTED;
+}
+
+}  // namespace gic

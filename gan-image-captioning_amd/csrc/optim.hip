@@ -1,0 +1,194 @@
+// GAN losses (reference src/utils.py:10-53), cross-entropy of the MLE pre-train step
+// (src/training.py:81-83) and the fused clip_grad_norm_ + Adam update over a flat parameter
+// arena (src/training.py:194-199).  All memory-bound; reductions use wavefront (64-lane)
+// shuffles and one LDS hop per block, and are deterministic (fixed partial order).
+#include "../../include/gicap.h"
+#include "kernels.h"
+
+namespace gic {
+namespace {
+
+__device__ __forceinline__ float softplusf_(float z) { return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))); }
+__device__ __forceinline__ float sigm_(float z) { return 1.f / (1.f + expf(-z)); }
+
+// One block: means over n logits + elementwise gradients (upstream gradient = 1 for each loss).
+__global__ __launch_bounds__(1024) void gan_losses_kernel(int type, const float* __restrict__ dr, const float* __restrict__ df,
+                                                           const float* __restrict__ go, long n, float* __restrict__ losses,
+                                                           float* __restrict__ dd_real, float* __restrict__ dd_fake,
+                                                           float* __restrict__ dg_out, float* __restrict__ dg_real,
+                                                           float* __restrict__ dg_fake) {
+  __shared__ float red[16];
+  const float inv = 1.f / (float)n;
+  float sd = 0.f, sg = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float r = dr[i], f = df[i], g = go[i];
+    float ld = 0.f, lg = 0.f, gdr = 0.f, gdf = 0.f, ggo = 0.f, ggr = 0.f, ggf = 0.f;
+    switch (type) {
+      case GIC_LOSS_STANDARD:
+      case GIC_LOSS_JS:
+      case GIC_LOSS_KL:
+        ld = softplusf_(-r) + softplusf_(f);           // BCE(d_real,1) + BCE(d_fake,0)
+        gdr = sigm_(r) - 1.f; gdf = sigm_(f);
+        if (type == GIC_LOSS_STANDARD) { lg = softplusf_(-g); ggo = sigm_(g) - 1.f; }
+        else if (type == GIC_LOSS_JS) { lg = -softplusf_(g); ggo = -sigm_(g); }
+        else { lg = -g; ggo = -1.f; }
+        break;
+      case GIC_LOSS_HINGE:
+        ld = fmaxf(1.f - r, 0.f) + fmaxf(1.f + f, 0.f);
+        gdr = (1.f - r) > 0.f ? -1.f : 0.f; gdf = (1.f + f) > 0.f ? 1.f : 0.f;
+        lg = -g; ggo = -1.f;
+        break;
+      case GIC_LOSS_TV: {
+        const float tr = tanhf(r), tf = tanhf(f), tg = tanhf(g);
+        ld = tf - tr; gdr = -(1.f - tr * tr); gdf = 1.f - tf * tf;
+        lg = -tg; ggo = -(1.f - tg * tg);
+      } break;
+      case GIC_LOSS_RSGAN:
+        ld = softplusf_(-(r - f)); gdr = sigm_(r - f) - 1.f; gdf = -gdr;
+        lg = softplusf_(-(f - r)); ggf = sigm_(f - r) - 1.f; ggr = -ggf;
+        break;
+      default: break;
+    }
+    sd += ld; sg += lg;
+    if (dd_real) dd_real[i] = gdr * inv;
+    if (dd_fake) dd_fake[i] = gdf * inv;
+    if (dg_out) dg_out[i] = ggo * inv;
+    if (dg_real) dg_real[i] = ggr * inv;
+    if (dg_fake) dg_fake[i] = ggf * inv;
+  }
+  sd = block_sum(sd, red);
+  sg = block_sum(sg, red);
+  if (threadIdx.x == 0) { losses[0] = sg * inv; losses[1] = sd * inv; }
+}
+
+// CrossEntropyLoss (mean over all rows, no ignore_index): per-row block; loss partial per row, summed by a tail kernel
+template <typename TA>
+__global__ __launch_bounds__(256) void xent_rows_kernel(const TA* __restrict__ logits, long rows, int V,
+                                                         const int64_t* __restrict__ targets, float* __restrict__ row_loss,
+                                                         TA* __restrict__ dlogits) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const TA* x = logits + row * V;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, to_f32<TA>(x[v]));
+  mx = block_max(mx, red);
+  float s = 0.f;
+  for (int v = threadIdx.x; v < V; v += 256) s += expf(to_f32<TA>(x[v]) - mx);
+  s = block_sum(s, red);
+  long tgt = targets[row];
+  tgt = tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt);
+  const float lse = mx + logf(s);
+  if (threadIdx.x == 0) row_loss[row] = lse - to_f32<TA>(x[tgt]);
+  if (dlogits) {
+    const float inv_rows = 1.f / (float)rows;
+    for (int v = threadIdx.x; v < V; v += 256) {
+      const float p = expf(to_f32<TA>(x[v]) - mx) / s;
+      dlogits[row * V + v] = from_f32<TA>((p - (v == tgt ? 1.f : 0.f)) * inv_rows);
+    }
+  }
+}
+__global__ __launch_bounds__(1024) void mean_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+
+// ---- clip + Adam -----------------------------------------------------------------------------
+constexpr int kNormBlock = 256;
+constexpr long kNormElemsPerBlock = 256 * 16;
+
+__global__ __launch_bounds__(kNormBlock) void sqnorm_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ partials,
+                                                                     int64_t* __restrict__ step_count) {
+  __shared__ float red[16];
+  const long base = (long)blockIdx.x * kNormElemsPerBlock;
+  float s = 0.f;
+  for (long i = base + threadIdx.x; i < base + kNormElemsPerBlock && i < n; i += kNormBlock) { const float v = g[i]; s += v * v; }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = s;
+    if (blockIdx.x == 0) step_count[0] += 1;       // optimizer step counter lives on the device (graph-replay safe)
+  }
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                         float clip_norm, const int64_t* __restrict__ step_count,
+                                                         const float* __restrict__ partials, int nparts, float* __restrict__ norm_out) {
+  __shared__ float red[16];
+  // every block re-reduces the (few) partials in the same order -> identical clip coefficient everywhere
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += partials[i];
+  s = block_sum(s, red);
+  const float norm = sqrtf(s);
+  if (blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = norm;
+  float coef = clip_norm / (norm + 1e-6f);           // torch.nn.utils.clip_grad_norm_
+  coef = coef > 1.f ? 1.f : coef;
+  const double t = (double)step_count[0];
+  const float bc1 = (float)(1.0 - pow((double)b1, t));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i] * coef;
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);        // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+}  // namespace
+}  // namespace gic
+
+using namespace gic;
+
+extern "C" {
+
+int gic_gan_losses(int loss_type, const float* d_real, const float* d_fake, const float* g_out, int64_t n, float* losses,
+                   float* dd_real, float* dd_fake, float* dg_out, float* dg_real, float* dg_fake, void* stream) {
+  GIC_CHECK_ARG(loss_type >= GIC_LOSS_STANDARD && loss_type <= GIC_LOSS_RSGAN, "gan_losses: unknown loss type %d", loss_type);
+  GIC_CHECK_ARG(d_real && d_fake && g_out && losses && n > 0, "gan_losses: null pointer or n<=0");
+  hipLaunchKernelGGL(gan_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, loss_type, d_real, d_fake, g_out, (long)n, losses,
+                     dd_real, dd_fake, dg_out, dg_real, dg_fake);
+  GIC_CHECK_LAUNCH("gan_losses");
+  return GIC_OK;
+}
+
+// `loss`: device f32[1 + rows]: loss[0] = mean, loss[1..] = per-row scratch.
+int gic_xent(const void* logits, int dtype, int64_t rows, int32_t V, const int64_t* targets, float* loss, void* d_logits, void* stream_) {
+  GIC_CHECK_ARG(logits && targets && loss && rows > 0 && V > 0, "xent: bad argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL((xent_rows_kernel<float>), dim3((unsigned)rows), dim3(256), 0, stream, (const float*)logits, (long)rows, V, targets,
+                       loss + 1, (float*)d_logits);
+  else if (dtype == DT_BF16)
+    hipLaunchKernelGGL((xent_rows_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, stream, (const bf16_t*)logits, (long)rows, V, targets,
+                       loss + 1, (bf16_t*)d_logits);
+  else { set_last_error("xent: bad dtype %d", dtype); return GIC_ERR_UNSUPPORTED; }
+  GIC_CHECK_LAUNCH("xent_rows");
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, stream, (const float*)(loss + 1), (long)rows, loss);
+  GIC_CHECK_LAUNCH("xent_mean");
+  return GIC_OK;
+}
+
+int64_t gic_clip_adam_partials(int64_t n) { return (n + kNormElemsPerBlock - 1) / kNormElemsPerBlock; }
+
+int gic_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float clip_norm, int64_t* step_count, float* norm_out, float* partials, void* stream_) {
+  GIC_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && step_count && norm_out && partials, "clip_adam: null pointer");
+  GIC_CHECK_ARG(n > 0, "clip_adam: n<=0");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nparts = (int)gic_clip_adam_partials(n);
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nparts), dim3(kNormBlock), 0, stream, grads, (long)n, partials, step_count);
+  GIC_CHECK_LAUNCH("sqnorm_partial");
+  long blocks = (n + 256 * 8 - 1) / (256 * 8);
+  blocks = blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, (long)n, lr,
+                     beta1, beta2, eps, clip_norm, (const int64_t*)step_count, (const float*)partials, nparts, norm_out);
+  GIC_CHECK_LAUNCH("clip_adam");
+  return GIC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,475 @@
+"""Tensor-level host wrappers around the C ABI: buffer planning + ctypes calls.
+
+``DecoderEngine`` / ``DiscEngine`` own nothing but the derived compute-dtype weight
+images; every other buffer (outputs, saved-for-backward state, workspaces, grads) is a
+torch tensor allocated here through PyTorch's caching allocator and handed to the
+library as a raw device pointer.  All launches go to the current PyTorch HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+TORCH_DTYPE = {L.F32: torch.float32, L.BF16: torch.bfloat16}
+DTYPE_BY_NAME = {"fp32": L.F32, "f32": L.F32, "float32": L.F32, "bf16": L.BF16, "bfloat16": L.BF16}
+
+_param_epoch = 0   # bumped by optimizers that update weights through raw pointers
+
+
+def bump_param_epoch() -> None:
+    global _param_epoch
+    _param_epoch += 1
+
+
+def parse_dtype(x) -> int:
+    if isinstance(x, int):
+        return x
+    try:
+        return DTYPE_BY_NAME[str(x).lower()]
+    except KeyError:
+        raise ValueError(f"unknown compute dtype {x!r} (use 'bf16' or 'fp32')")
+
+
+def require_gpu(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise L.GicError("tensor is not on a GPU: the hot path runs only through the HIP library "
+                             "(libgicap.so) on an AMD GPU and has no CPU fallback")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _arr(ctype, n, values):
+    a = (ctype * n)()
+    for i, v in enumerate(values):
+        a[i] = v
+    return a
+
+
+def _key(params: Sequence[torch.Tensor]):
+    return tuple((p.data_ptr(), p._version) for p in params) + (_param_epoch,)
+
+
+# ------------------------------------------------------------------------------------------ generic ops
+def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, accumulate=False, alpha=1.0):
+    require_gpu(A, B, Cout)
+    in_dt = L.F32 if A.dtype == torch.float32 else L.BF16
+    out_dt = L.F32 if Cout.dtype == torch.float32 else L.BF16
+    L.check(L.load().gic_gemm(ptr(A), ptr(B), ptr(Cout), M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc), in_dt, out_dt,
+                              ptr(bias), int(accumulate), float(alpha), stream_ptr()), "gic_gemm")
+    return Cout
+
+
+def cast2d(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int, lds: int, ldd: int):
+    require_gpu(src, dst)
+    sd = L.F32 if src.dtype == torch.float32 else L.BF16
+    dd = L.F32 if dst.dtype == torch.float32 else L.BF16
+    L.check(L.load().gic_cast2d(ptr(src), sd, lds, ptr(dst), dd, ldd, rows, cols, stream_ptr()), "gic_cast2d")
+    return dst
+
+
+def embedding_fwd(weight: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    require_gpu(weight, ids)
+    ids = ids.contiguous()
+    out = torch.empty(ids.numel(), weight.shape[1], device=weight.device, dtype=torch.float32)
+    L.check(L.load().gic_embedding_fwd(ptr(weight), ptr(ids), ptr(out), ids.numel(), weight.shape[0], weight.shape[1],
+                                       stream_ptr()), "gic_embedding_fwd")
+    return out.view(*ids.shape, weight.shape[1])
+
+
+def embedding_bwd(d_out: torch.Tensor, ids: torch.Tensor, V: int, d_weight: Optional[torch.Tensor] = None,
+                  zero_first: bool = True) -> torch.Tensor:
+    require_gpu(d_out, ids)
+    E = d_out.shape[-1]
+    d_out = d_out.contiguous()
+    ids = ids.contiguous()
+    if d_weight is None:
+        d_weight = torch.empty(V, E, device=d_out.device, dtype=torch.float32)
+    L.check(L.load().gic_embedding_bwd(ptr(d_out), ptr(ids), ptr(d_weight), ids.numel(), V, E, int(zero_first), stream_ptr()),
+            "gic_embedding_bwd")
+    return d_weight
+
+
+def gan_losses(loss_type: str, d_real, d_fake, g_out, want_grads: bool = True):
+    """Returns (losses[2] device tensor: [g_loss, d_loss], grads dict or None)."""
+    if loss_type not in L.LOSS_TYPES:
+        raise NotImplementedError("Divergence '%s' is not implemented" % loss_type)   # utils.py:50-51
+    require_gpu(d_real, d_fake, g_out)
+    d_real, d_fake, g_out = d_real.contiguous(), d_fake.contiguous(), g_out.contiguous()
+    n = d_real.numel()
+    losses = torch.empty(2, device=d_real.device, dtype=torch.float32)
+    g = None
+    if want_grads:
+        buf = torch.empty(5, n, device=d_real.device, dtype=torch.float32)
+        g = {"dd_real": buf[0], "dd_fake": buf[1], "dg_out": buf[2], "dg_real": buf[3], "dg_fake": buf[4]}
+    L.check(L.load().gic_gan_losses(L.LOSS_TYPES[loss_type], ptr(d_real), ptr(d_fake), ptr(g_out), n, ptr(losses),
+                                    ptr(g["dd_real"]) if g else None, ptr(g["dd_fake"]) if g else None,
+                                    ptr(g["dg_out"]) if g else None, ptr(g["dg_real"]) if g else None,
+                                    ptr(g["dg_fake"]) if g else None, stream_ptr()), "gic_gan_losses")
+    return losses, g
+
+
+def xent(logits: torch.Tensor, targets: torch.Tensor, want_grad: bool = True):
+    """CrossEntropyLoss(mean over all rows). logits [rows,V] (f32/bf16, contiguous). Returns (loss[1], d_logits|None)."""
+    require_gpu(logits, targets)
+    rows, V = logits.shape
+    dt = L.F32 if logits.dtype == torch.float32 else L.BF16
+    buf = torch.empty(1 + rows, device=logits.device, dtype=torch.float32)
+    dl = torch.empty_like(logits) if want_grad else None
+    L.check(L.load().gic_xent(ptr(logits), dt, rows, V, ptr(targets.contiguous()), ptr(buf), ptr(dl), stream_ptr()), "gic_xent")
+    return buf[:1], dl
+
+
+# ------------------------------------------------------------------------------------------ decoder
+class DecoderEngine:
+    """Decoder.sample forward/backward (reference src/generator.py:55-96) on the HIP library."""
+
+    def __init__(self, vocab: int, embed: int, hidden: int, layers: int, dtype: int):
+        if not 1 <= layers <= L.MAX_LAYERS:
+            raise ValueError(f"gen_num_layers must be in 1..{L.MAX_LAYERS}")
+        self.V, self.E, self.H, self.NL, self.dt = vocab, embed, hidden, layers, dtype
+        self.act = TORCH_DTYPE[dtype]
+        self._shadow: Optional[Dict[str, object]] = None
+        self._shadow_key = None
+
+    def din(self, l: int) -> int:
+        return self.E if l == 0 else self.H
+
+    def ldx(self, l: int) -> int:
+        return self.din(l) + self.H
+
+    def dims(self, B: int, Lc: int) -> L.DecoderDims:
+        return L.DecoderDims(B, Lc, self.V, self.E, self.H, self.NL, self.dt)
+
+    # params: [embed, (w_ih, w_hh, b_ih, b_hh) * NL, w_out, b_out]
+    def _pstruct(self, params, cls=L.DecoderParams, extra=None):
+        nl = self.NL
+        s = cls()
+        s.embed = ptr(params[0])
+        s.w_ih = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(params[1 + 4 * l]) for l in range(nl)])
+        s.w_hh = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(params[2 + 4 * l]) for l in range(nl)])
+        s.b_ih = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(params[3 + 4 * l]) for l in range(nl)])
+        s.b_hh = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(params[4 + 4 * l]) for l in range(nl)])
+        s.w_out = ptr(params[1 + 4 * nl])
+        s.b_out = ptr(params[2 + 4 * nl])
+        if extra is not None:
+            s.features = ptr(extra)
+        return s
+
+    def check_params(self, params) -> None:
+        if len(params) != 3 + 4 * self.NL:
+            raise ValueError("decoder expects embed, 4 tensors per LSTM layer, linear weight and bias")
+        require_gpu(*params)
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError("decoder parameters must be contiguous float32 (master weights)")
+
+    def prepare(self, params) -> Dict[str, object]:
+        """Refresh the compute-dtype weight images if any master weight changed."""
+        key = _key(params)
+        if self._shadow is not None and key == self._shadow_key:
+            return self._shadow
+        dev = params[0].device
+        if self._shadow is None or self._shadow["wcat"][0].device != dev:
+            self._shadow = {
+                "wcat": [torch.empty(4 * self.H, self.ldx(l), device=dev, dtype=self.act) for l in range(self.NL)],
+                "bsum": [torch.empty(4 * self.H, device=dev, dtype=torch.float32) for l in range(self.NL)],
+                "wout": None if self.dt == L.F32 else torch.empty(self.V, self.H, device=dev, dtype=self.act),
+            }
+        sh = self._shadow
+        s = self._shadow_struct(params)
+        d = self.dims(1, 1)
+        L.check(L.load().gic_decoder_prepare(C.byref(d), C.byref(self._pstruct(params)), C.byref(s), stream_ptr()),
+                "gic_decoder_prepare")
+        self._shadow_key = key
+        return sh
+
+    def _shadow_struct(self, params) -> L.DecoderShadow:
+        sh = self._shadow
+        s = L.DecoderShadow()
+        s.wcat = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in sh["wcat"]])
+        s.bsum = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in sh["bsum"]])
+        s.wout = ptr(params[1 + 4 * self.NL]) if sh["wout"] is None else ptr(sh["wout"])
+        return s
+
+    def alloc_state(self, B: int, Lc: int, dev) -> Dict[str, object]:
+        f32 = torch.float32
+        return {
+            "xh": [torch.empty(Lc + 1, B, self.ldx(l), device=dev, dtype=self.act) for l in range(self.NL)],
+            "gates": [torch.empty(Lc, B, 4 * self.H, device=dev, dtype=f32) for _ in range(self.NL)],
+            "c": [torch.empty(Lc + 1, B, self.H, device=dev, dtype=f32) for _ in range(self.NL)],
+            "hout": torch.empty(B, Lc, self.H, device=dev, dtype=self.act),
+            "logits": torch.empty(B, self.V, device=dev, dtype=f32),
+            "gpre": torch.empty(B, 4 * self.H, device=dev, dtype=f32),
+        }
+
+    def _state_struct(self, st) -> L.DecoderState:
+        s = L.DecoderState()
+        s.xh = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in st["xh"]])
+        s.gates = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in st["gates"]])
+        s.c = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in st["c"]])
+        s.hout, s.logits, s.gpre = ptr(st["hout"]), ptr(st["logits"]), ptr(st["gpre"])
+        return s
+
+    def alloc_bwd_ws(self, B: int, Lc: int, dev) -> Dict[str, object]:
+        f32 = torch.float32
+        return {
+            "dlogits": torch.empty(B, Lc, self.V, device=dev, dtype=self.act),
+            "dhout": torch.empty(B, Lc, self.H, device=dev, dtype=f32),
+            "dgates": [torch.empty(Lc, B, 4 * self.H, device=dev, dtype=self.act) for _ in range(self.NL)],
+            "dxh": [torch.empty(Lc + 1, B, self.ldx(l), device=dev, dtype=f32) for l in range(self.NL)],
+            "dc": [torch.empty(B, self.H, device=dev, dtype=f32) for _ in range(self.NL)],
+        }
+
+    def alloc_grads(self, params, B: int) -> List[torch.Tensor]:
+        """[d_embed, per-layer grads..., d_w_out, d_b_out, d_features]"""
+        g = [torch.empty_like(p) for p in params]
+        g.append(torch.empty(B, self.E, device=params[0].device, dtype=torch.float32))
+        return g
+
+    def sample_fwd(self, params, features: torch.Tensor, Lc: int, temperature: float, pretrain: bool = False,
+                   noise_u: Optional[torch.Tensor] = None, seed: int = 0, state=None, out=None, ids=None):
+        self.check_params(params)
+        require_gpu(features, noise_u)
+        B = features.shape[0]
+        if features.shape != (B, self.E) or features.dtype != torch.float32:
+            raise ValueError(f"features must be float32 [B,{self.E}], got {tuple(features.shape)} {features.dtype}")
+        features = features.contiguous()
+        dev = features.device
+        if noise_u is not None:
+            if tuple(noise_u.shape) != (Lc, B, self.V) or noise_u.dtype != torch.float32:
+                raise ValueError(f"noise_u must be float32 [L={Lc},B={B},V={self.V}]")
+            noise_u = noise_u.contiguous()
+        self.prepare(params)
+        st = state if state is not None else self.alloc_state(B, Lc, dev)
+        out = out if out is not None else torch.empty(B, Lc, self.V, device=dev, dtype=self.act)
+        ids = ids if ids is not None else torch.empty(B, Lc, device=dev, dtype=torch.int64)
+        d = self.dims(B, Lc)
+        L.check(L.load().gic_decoder_sample_fwd(
+            C.byref(d), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
+            ptr(features), ptr(noise_u), int(seed) & (2 ** 64 - 1), float(temperature), int(bool(pretrain)), ptr(out), ptr(ids),
+            stream_ptr()), "gic_decoder_sample_fwd")
+        return out, ids, st
+
+    def sample_bwd(self, params, st, out: torch.Tensor, ids: torch.Tensor, d_out: torch.Tensor, temperature: float,
+                   pretrain: bool = False, ws=None, grads=None) -> List[torch.Tensor]:
+        B, Lc = ids.shape
+        dev = out.device
+        if d_out.dtype != self.act:
+            d_out = self._cast_like(d_out)
+        d_out = d_out.contiguous()
+        self.prepare(params)
+        ws = ws if ws is not None else self.alloc_bwd_ws(B, Lc, dev)
+        grads = grads if grads is not None else self.alloc_grads(params, B)
+        w = L.DecoderBwdWs()
+        w.dlogits, w.dhout = ptr(ws["dlogits"]), ptr(ws["dhout"])
+        w.dgates = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in ws["dgates"]])
+        w.dxh = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in ws["dxh"]])
+        w.dc = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in ws["dc"]])
+        d = self.dims(B, Lc)
+        L.check(L.load().gic_decoder_sample_bwd(
+            C.byref(d), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
+            C.byref(w), ptr(out), ptr(ids), ptr(d_out), float(temperature), int(bool(pretrain)),
+            C.byref(self._pstruct(grads[:-1], L.DecoderGrads, grads[-1])), stream_ptr()), "gic_decoder_sample_bwd")
+        return grads
+
+    def _cast_like(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.contiguous()
+        dst = torch.empty(t.shape, device=t.device, dtype=self.act)
+        n = t.shape[-1]
+        cast2d(t, dst, t.numel() // n, n, n, n)
+        return dst
+
+
+# ------------------------------------------------------------------------------------------ discriminator
+class DiscEngine:
+    """Discriminator.forward/backward (reference src/discriminator.py:34-62) on the HIP library."""
+
+    OUT = 100
+    OUT_PAD = 104
+
+    def __init__(self, vocab: int, embed_dim: int, num_rep: int, filter_sizes: Sequence[int], num_filters: Sequence[int], dtype: int):
+        if len(filter_sizes) != len(num_filters) or not 1 <= len(filter_sizes) <= L.MAX_CONVS:
+            raise ValueError("disc_filter_sizes / disc_num_filters must have equal length in 1..%d" % L.MAX_CONVS)
+        if embed_dim % num_rep:
+            raise ValueError("disc_embed_dim must be a multiple of disc_num_rep")
+        self.V, self.De, self.R = vocab, embed_dim, num_rep
+        self.fs, self.nf = list(filter_sizes), list(num_filters)
+        self.F = sum(self.nf)
+        self.Fp = (self.F + 7) // 8 * 8
+        self.s = embed_dim // num_rep
+        self.dt = dtype
+        self.act = TORCH_DTYPE[dtype]
+        self._shadow = None
+        self._shadow_key = None
+
+    # params: [emb, (conv_w, conv_b)*nconv, hw_w, hw_b, f2o_w, f2o_b, o2l_w, o2l_b]
+    def nparams(self) -> int:
+        return 7 + 2 * len(self.fs)
+
+    def dims(self, B: int, Lc: int) -> L.DiscDims:
+        d = L.DiscDims()
+        d.B, d.L, d.V, d.De, d.R, d.nconv = B, Lc, self.V, self.De, self.R, len(self.fs)
+        d.fsize = _arr(C.c_int32, L.MAX_CONVS, self.fs)
+        d.nfilt = _arr(C.c_int32, L.MAX_CONVS, self.nf)
+        d.F, d.Fp, d.dtype = self.F, self.Fp, self.dt
+        return d
+
+    def _pstruct(self, params, cls=L.DiscParams):
+        n = len(self.fs)
+        s = cls()
+        s.emb = ptr(params[0])
+        s.conv_w = _arr(C.c_void_p, L.MAX_CONVS, [ptr(params[1 + 2 * k]) for k in range(n)])
+        s.conv_b = _arr(C.c_void_p, L.MAX_CONVS, [ptr(params[2 + 2 * k]) for k in range(n)])
+        o = 1 + 2 * n
+        s.hw_w, s.hw_b, s.f2o_w, s.f2o_b, s.o2l_w, s.o2l_b = (ptr(params[o + i]) for i in range(6))
+        return s
+
+    def check_params(self, params) -> None:
+        if len(params) != self.nparams():
+            raise ValueError("discriminator expects %d parameter tensors" % self.nparams())
+        require_gpu(*params)
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError("discriminator parameters must be contiguous float32 (master weights)")
+
+    def prepare(self, params):
+        key = _key(params)
+        if self._shadow is not None and key == self._shadow_key:
+            return self._shadow
+        dev = params[0].device
+        if self._shadow is None or self._shadow["hw_w"].device != dev:
+            self._shadow = {
+                "emb": None if self.dt == L.F32 else torch.empty(self.De, self.V, device=dev, dtype=self.act),
+                "hw_w": torch.empty(self.Fp, self.Fp, device=dev, dtype=self.act),
+                "f2o_w": torch.empty(self.OUT_PAD, self.Fp, device=dev, dtype=self.act),
+            }
+        d = self.dims(1, max(self.fs))
+        L.check(L.load().gic_disc_prepare(C.byref(d), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)),
+                                          stream_ptr()), "gic_disc_prepare")
+        self._shadow_key = key
+        return self._shadow
+
+    def _shadow_struct(self, params) -> L.DiscShadow:
+        sh = self._shadow
+        s = L.DiscShadow()
+        s.emb = ptr(params[0]) if sh["emb"] is None else ptr(sh["emb"])
+        s.hw_w, s.f2o_w = ptr(sh["hw_w"]), ptr(sh["f2o_w"])
+        return s
+
+    def alloc_state(self, B: int, Lc: int, dev):
+        f32, u8 = torch.float32, torch.uint8
+        MR = B * self.R
+        return {
+            "emb": torch.empty(B * Lc, self.De, device=dev, dtype=f32),
+            "pooled": torch.empty(MR, self.Fp, device=dev, dtype=self.act),
+            "argmax": torch.empty(MR, self.Fp, device=dev, dtype=u8),
+            "hpre": torch.empty(MR, self.Fp, device=dev, dtype=f32),
+            "keep": torch.empty(MR, self.Fp, device=dev, dtype=u8),
+            "ydrop": torch.zeros(MR, self.Fp, device=dev, dtype=self.act),    # pad columns must stay zero
+            "feat": torch.empty(MR, self.OUT, device=dev, dtype=f32),
+        }
+
+    def _state_struct(self, st) -> L.DiscState:
+        s = L.DiscState()
+        for k in ("emb", "pooled", "argmax", "hpre", "keep", "ydrop", "feat"):
+            setattr(s, k, ptr(st[k]))
+        return s
+
+    def alloc_bwd_ws(self, B: int, Lc: int, dev):
+        f32 = torch.float32
+        MR = B * self.R
+        return {
+            "dfeat": torch.empty(MR, self.OUT_PAD, device=dev, dtype=self.act),
+            "dh": torch.empty(MR, self.Fp, device=dev, dtype=self.act),
+            "dydrop": torch.empty(MR, self.Fp, device=dev, dtype=f32),
+            "dpooled": torch.empty(MR, self.Fp, device=dev, dtype=f32),
+            "demb": torch.empty(B * Lc, self.De, device=dev, dtype=self.act),
+        }
+
+    def soft_input(self, inp: torch.Tensor) -> torch.Tensor:
+        """[B,L,V] float tensor -> contiguous compute-dtype tensor (converted by gic_cast2d if needed)."""
+        if inp.dim() != 3 or inp.shape[2] != self.V:
+            raise ValueError(f"discriminator input must be [B, L, V={self.V}], got {tuple(inp.shape)}")
+        require_gpu(inp)
+        if inp.dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("discriminator input must be float32 or bfloat16")
+        inp = inp.contiguous()
+        if inp.dtype != self.act:
+            dst = torch.empty(inp.shape, device=inp.device, dtype=self.act)
+            cast2d(inp, dst, inp.shape[0] * inp.shape[1], self.V, self.V, self.V)
+            inp = dst
+        return inp
+
+    def fwd(self, params, inp_soft: Optional[torch.Tensor], inp_ids: Optional[torch.Tensor], train: bool,
+            keep_mask: Optional[torch.Tensor] = None, seed: int = 0, state=None, logits=None):
+        self.check_params(params)
+        src = inp_soft if inp_soft is not None else inp_ids
+        require_gpu(src, keep_mask)
+        B, Lc = src.shape[0], src.shape[1]
+        dev = src.device
+        if inp_ids is not None:
+            if inp_ids.dtype != torch.int64:
+                raise ValueError("token ids must be int64")
+            inp_ids = inp_ids.contiguous()
+        if keep_mask is not None:
+            if tuple(keep_mask.shape) != (B * self.R, self.F):
+                raise ValueError(f"keep_mask must be [B*R={B * self.R}, F={self.F}]")
+            keep_mask = keep_mask.to(torch.uint8).contiguous()
+        self.prepare(params)
+        st = state if state is not None else self.alloc_state(B, Lc, dev)
+        logits = logits if logits is not None else torch.empty(B * self.R, device=dev, dtype=torch.float32)
+        d = self.dims(B, Lc)
+        L.check(L.load().gic_disc_fwd(
+            C.byref(d), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
+            ptr(inp_soft), self.V, ptr(inp_ids), int(bool(train)), ptr(keep_mask), int(seed) & (2 ** 64 - 1), ptr(logits),
+            stream_ptr()), "gic_disc_fwd")
+        return logits, st
+
+    def bwd(self, params, st, inp_soft, inp_ids, train: bool, d_logits: torch.Tensor, want_param_grads: bool,
+            want_input_grad: bool, grads=None, accumulate: bool = False, ws=None, d_inp=None):
+        src = inp_soft if inp_soft is not None else inp_ids
+        B, Lc = src.shape[0], src.shape[1]
+        dev = src.device
+        d_logits = d_logits.contiguous().float()
+        self.prepare(params)
+        ws = ws if ws is not None else self.alloc_bwd_ws(B, Lc, dev)
+        if want_param_grads and grads is None:
+            grads = [torch.empty_like(p) for p in params]
+            accumulate = False
+        if want_input_grad and d_inp is None:
+            d_inp = torch.empty(B, Lc, self.V, device=dev, dtype=self.act)
+        w = L.DiscBwdWs()
+        for k in ("dfeat", "dh", "dydrop", "dpooled", "demb"):
+            setattr(w, k, ptr(ws[k]))
+        d = self.dims(B, Lc)
+        gs = self._pstruct(grads, L.DiscGrads) if want_param_grads else None
+        L.check(L.load().gic_disc_bwd(
+            C.byref(d), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
+            C.byref(w), ptr(inp_soft), self.V, ptr(inp_ids), int(bool(train)), ptr(d_logits),
+            C.byref(gs) if gs is not None else None, int(bool(accumulate)), ptr(d_inp) if want_input_grad else None, self.V,
+            stream_ptr()), "gic_disc_bwd")
+        return (grads if want_param_grads else None), (d_inp if want_input_grad else None)
+
+
+# ------------------------------------------------------------------------------------------ fused clip + Adam
+def clip_adam_partials(n: int) -> int:
+    return int(L.load().gic_clip_adam_partials(n))
+
+
+def clip_adam(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, clip_norm, step_count, norm_out, partials):
+    require_gpu(params, grads, exp_avg, exp_avg_sq, step_count, norm_out, partials)
+    L.check(L.load().gic_clip_adam(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), params.numel(), float(lr), float(beta1),
+                                   float(beta2), float(eps), float(clip_norm), ptr(step_count), ptr(norm_out), ptr(partials),
+                                   stream_ptr()), "gic_clip_adam")
+    bump_param_epoch()

@@ -1,0 +1,235 @@
+/* gicap.h - C ABI of libgicap.so: hand-written HIP (gfx950 / MI355X) kernels for the
+ * adversarial image-captioning train step.
+ *
+ * The reference (kawshik8/GAN-Image-Captioning) has no FFI: its boundary for this
+ * path is the Python module API consumed by src/training.py.  Each entry point below
+ * therefore cites the reference interface whose compute it replaces (file:line under
+ * /root/reference/); the Python host in gan-image-captioning_amd/ keeps the module
+ * API and binds these symbols with ctypes.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; every pointer is DEVICE memory unless named host_*.
+ *  - the caller owns every buffer (parameters, outputs, saved-for-backward state,
+ *    workspaces); the library allocates nothing and keeps no global state except
+ *    the thread-local last-error string.
+ *  - every function enqueues on `stream` (a hipStream_t passed as void*) and returns
+ *    immediately: 0 = OK, negative = gic_status.  No exceptions, no exit().
+ *  - dtype: GIC_F32 (parity mode; exact-f32 MFMA) or GIC_BF16 (bf16 MFMA operands,
+ *    f32 accumulation, f32 master weights / grads / optimizer state).
+ *    "act" buffers below have the compute dtype; everything else is f32.
+ */
+#ifndef GICAP_H_
+#define GICAP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GIC_ABI_VERSION 1
+#define GIC_MAX_LAYERS 4
+#define GIC_MAX_CONVS 8
+
+enum gic_status {
+  GIC_STATUS_OK = 0,
+  GIC_STATUS_INVALID_ARG = -1,
+  GIC_STATUS_UNSUPPORTED = -2,
+  GIC_STATUS_LAUNCH = -3,
+  GIC_STATUS_WORKSPACE = -4
+};
+enum gic_dtype { GIC_F32 = 0, GIC_BF16 = 1 };
+enum gic_loss_type {           /* src/utils.py:10-53 */
+  GIC_LOSS_STANDARD = 0, GIC_LOSS_JS = 1, GIC_LOSS_KL = 2, GIC_LOSS_HINGE = 3, GIC_LOSS_TV = 4, GIC_LOSS_RSGAN = 5
+};
+
+int gic_abi_version(void);
+/* Message of the last failing call on this host thread ("" if none). */
+const char* gic_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Generic dense contraction (used by the tests and by every entry point below).
+ *   C[m,n] = alpha * sum_k A(m,k) B(n,k) + bias[n]  (+ C if accumulate)
+ *   A(m,k) = a_kc ? A[m*lda+k] : A[k*lda+m];  B(n,k) = b_kc ? B[n*ldb+k] : B[k*ldb+n]
+ * Replaces the ATen GEMMs behind nn.Linear / nn.LSTM / autograd (generator.py:61,68;
+ * discriminator.py:40,53,58,60).
+ */
+int gic_gemm(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+             int a_kc, int b_kc, int in_dtype, int out_dtype, const float* bias, int accumulate, float alpha,
+             void* stream);
+
+/* 2-D copy with dtype conversion: dst[r*ldd + c] = src[r*lds + c]. */
+int gic_cast2d(const void* src, int src_dtype, int64_t lds, void* dst, int dst_dtype, int64_t ldd,
+               int64_t rows, int64_t cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Generator: Decoder.sample (src/generator.py:55-96) forward + backward.
+ */
+typedef struct gic_decoder_dims {
+  int32_t B, L, V, E, H, NL;   /* batch, max_caption_len, vocab, gen_embed_dim, gen_hidden_dim, gen_num_layers */
+  int32_t dtype;               /* compute dtype */
+} gic_decoder_dims;
+
+typedef struct gic_decoder_params {      /* f32 master weights, state-dict layout of nn.Embedding/nn.LSTM/nn.Linear */
+  const float* embed;                    /* decoder.embed.weight            [V,E]      */
+  const float* w_ih[GIC_MAX_LAYERS];     /* decoder.lstm.weight_ih_l{k}     [4H,Din_k] */
+  const float* w_hh[GIC_MAX_LAYERS];     /* decoder.lstm.weight_hh_l{k}     [4H,H]     */
+  const float* b_ih[GIC_MAX_LAYERS];     /* decoder.lstm.bias_ih_l{k}       [4H]       */
+  const float* b_hh[GIC_MAX_LAYERS];     /* decoder.lstm.bias_hh_l{k}       [4H]       */
+  const float* w_out;                    /* decoder.linear.weight           [V,H]      */
+  const float* b_out;                    /* decoder.linear.bias             [V]        */
+} gic_decoder_params;
+
+typedef struct gic_decoder_grads {       /* f32, same shapes as gic_decoder_params; all overwritten */
+  float* embed;
+  float* w_ih[GIC_MAX_LAYERS];
+  float* w_hh[GIC_MAX_LAYERS];
+  float* b_ih[GIC_MAX_LAYERS];
+  float* b_hh[GIC_MAX_LAYERS];
+  float* w_out;
+  float* b_out;
+  float* features;                       /* d(features) [B,E] */
+} gic_decoder_grads;
+
+/* Derived per-step weight images in the compute dtype (caller-owned, refreshed by gic_decoder_prepare). */
+typedef struct gic_decoder_shadow {
+  void* wcat[GIC_MAX_LAYERS];            /* act [4H, Din_k+H] = [w_ih | w_hh] */
+  float* bsum[GIC_MAX_LAYERS];           /* [4H] = b_ih + b_hh */
+  void* wout;                            /* act [V,H] (may alias params.w_out in f32 mode) */
+} gic_decoder_shadow;
+
+/* Saved-for-backward state + scratch of one sample() call (caller-owned). Din_0=E, Din_k=H. */
+typedef struct gic_decoder_state {
+  void* xh[GIC_MAX_LAYERS];              /* act [(L+1), B, Din_k+H]: LSTM input | previous hidden, time-major */
+  float* gates[GIC_MAX_LAYERS];          /* [L, B, 4H] post-activation i,f,g,o */
+  float* c[GIC_MAX_LAYERS];              /* [(L+1), B, H] cell state, slot 0 = zeros */
+  void* hout;                            /* act [B, L, H] last layer's h, batch-major (vocab GEMM operand) */
+  float* logits;                         /* scratch [B, V] */
+  float* gpre;                           /* scratch [B, 4H] */
+} gic_decoder_state;
+
+typedef struct gic_decoder_bwd_ws {      /* scratch for backward (caller-owned) */
+  void* dlogits;                         /* act [B, L, V] */
+  float* dhout;                          /* [B, L, H] */
+  void* dgates[GIC_MAX_LAYERS];          /* act [L, B, 4H] */
+  float* dxh[GIC_MAX_LAYERS];            /* [(L+1), B, Din_k+H] */
+  float* dc[GIC_MAX_LAYERS];             /* [B, H] */
+} gic_decoder_bwd_ws;
+
+int gic_decoder_prepare(const gic_decoder_dims* dims, const gic_decoder_params* params,
+                        const gic_decoder_shadow* shadow, void* stream);
+
+/* features [B,E] f32.  noise_u: explicit U[0,1) draws [L,B,V] f32 (generator.py:86-90 order) or NULL to
+ * draw on device with Philox(seed, step).  pretrain != 0: generator.py:63-66 (out = raw logits, feedback =
+ * argmax).  out: act [B,L,V] (probabilities or logits).  ids: int64 [B,L]. */
+int gic_decoder_sample_fwd(const gic_decoder_dims* dims, const gic_decoder_params* params,
+                           const gic_decoder_shadow* shadow, const gic_decoder_state* state,
+                           const float* features, const float* noise_u, uint64_t seed, float temperature,
+                           int pretrain, void* out, int64_t* ids, void* stream);
+
+/* d_out: act [B,L,V] gradient w.r.t. `out`; probs = the forward's `out`. */
+int gic_decoder_sample_bwd(const gic_decoder_dims* dims, const gic_decoder_params* params,
+                           const gic_decoder_shadow* shadow, const gic_decoder_state* state,
+                           const gic_decoder_bwd_ws* ws, const void* probs, const int64_t* ids,
+                           const void* d_out, float temperature, int pretrain,
+                           const gic_decoder_grads* grads, void* stream);
+
+/* nn.Embedding used as a callable (training.py:68,147): out[i,:] = weight[ids[i],:] and its scatter-add. */
+int gic_embedding_fwd(const float* weight, const int64_t* ids, float* out, int64_t n, int32_t V, int32_t E, void* stream);
+int gic_embedding_bwd(const float* d_out, const int64_t* ids, float* d_weight, int64_t n, int32_t V, int32_t E,
+                      int zero_first, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Discriminator.forward (src/discriminator.py:34-62) forward + backward.
+ */
+typedef struct gic_disc_dims {
+  int32_t B, L, V, De, R, nconv;         /* De=disc_embed_dim, R=disc_num_rep, s = De/R */
+  int32_t fsize[GIC_MAX_CONVS];          /* disc_filter_sizes */
+  int32_t nfilt[GIC_MAX_CONVS];          /* disc_num_filters */
+  int32_t F;                             /* sum(nfilt) */
+  int32_t Fp;                            /* leading dim of the [B*R, F] activations (>= F, multiple of 8) */
+  int32_t dtype;
+} gic_disc_dims;
+
+typedef struct gic_disc_params {
+  const float* emb;                      /* embeddings.weight  [De,V] */
+  const float* conv_w[GIC_MAX_CONVS];    /* convs.k.weight     [n_k,1,f_k,s] */
+  const float* conv_b[GIC_MAX_CONVS];    /* convs.k.bias       [n_k] */
+  const float* hw_w; const float* hw_b;  /* highway            [F,F],[F] */
+  const float* f2o_w; const float* f2o_b;/* feature2out        [100,F],[100] */
+  const float* o2l_w; const float* o2l_b;/* out2logits         [1,100],[1] */
+} gic_disc_params;
+
+typedef struct gic_disc_grads {          /* f32; accumulate != 0 adds to the existing contents */
+  float* emb; float* conv_w[GIC_MAX_CONVS]; float* conv_b[GIC_MAX_CONVS];
+  float* hw_w; float* hw_b; float* f2o_w; float* f2o_b; float* o2l_w; float* o2l_b;
+} gic_disc_grads;
+
+typedef struct gic_disc_shadow {         /* compute-dtype weight images (may alias params in f32 mode) */
+  void* emb;                             /* act [De,V] */
+  void* hw_w;                            /* act [F,F]  */
+  void* f2o_w;                           /* act [100,F] */
+} gic_disc_shadow;
+
+typedef struct gic_disc_state {          /* saved-for-backward of one forward call (caller-owned) */
+  float* emb;                            /* [B*L, De] */
+  void* pooled;                          /* act [B*R, Fp] conv+relu+max-over-time, row = b*R+r */
+  uint8_t* argmax;                       /* [B*R, Fp] time index of the max */
+  float* hpre;                           /* [B*R, Fp] highway pre-activation */
+  uint8_t* keep;                         /* [B*R, Fp] dropout keep mask actually used (train mode) */
+  void* ydrop;                           /* act [B*R, Fp] dropped highway output */
+  float* feat;                           /* [B*R, 100] */
+} gic_disc_state;
+
+typedef struct gic_disc_bwd_ws {
+  void* dfeat;                           /* act [B*R, 104] */
+  void* dh;                              /* act [B*R, Fp] */
+  float* dydrop;                         /* [B*R, Fp] */
+  float* dpooled;                        /* [B*R, Fp] */
+  float* demb;                           /* [B*L, De] */
+} gic_disc_bwd_ws;
+
+int gic_disc_prepare(const gic_disc_dims* dims, const gic_disc_params* params, const gic_disc_shadow* shadow, void* stream);
+
+/* Exactly one of inp_soft (act [B*L, V], row stride ld_inp, rows in (b,l) order) and inp_ids (int64 [B,L];
+ * the one-hot of training.py:158 evaluated as a gather) is non-NULL.
+ * train != 0: dropout(0.2) with keep_mask (uint8 0/1 [B*R,F], row stride F) or, if NULL, Philox(seed).
+ * logits: f32 [B*R]. */
+int gic_disc_fwd(const gic_disc_dims* dims, const gic_disc_params* params, const gic_disc_shadow* shadow,
+                 const gic_disc_state* state, const void* inp_soft, int64_t ld_inp, const int64_t* inp_ids,
+                 int train, const uint8_t* keep_mask, uint64_t seed, float* logits, void* stream);
+
+/* d_logits f32 [B*R].  grads may be NULL (no parameter gradients wanted: the generator's path,
+ * training.py:169).  d_inp: act [B*L, V] (row stride ld_dinp) or NULL. */
+int gic_disc_bwd(const gic_disc_dims* dims, const gic_disc_params* params, const gic_disc_shadow* shadow,
+                 const gic_disc_state* state, const gic_disc_bwd_ws* ws, const void* inp_soft, int64_t ld_inp,
+                 const int64_t* inp_ids, int train, const float* d_logits, const gic_disc_grads* grads,
+                 int accumulate, void* d_inp, int64_t ld_dinp, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * get_losses (src/utils.py:10-53): losses[0]=g_loss, losses[1]=d_loss (device scalars) and, when the
+ * d_* pointers are non-NULL, the gradients of d_loss w.r.t. (d_real, d_fake) and of g_loss w.r.t.
+ * (g_out, and for rsgan d_real/d_fake through dg_real/dg_fake).
+ */
+int gic_gan_losses(int loss_type, const float* d_real, const float* d_fake, const float* g_out, int64_t n,
+                   float* losses, float* dd_real, float* dd_fake, float* dg_out, float* dg_real, float* dg_fake,
+                   void* stream);
+
+/* CrossEntropyLoss over all rows (training.py:81-83): loss (device scalar) and d_logits = (softmax - onehot)/rows. */
+int gic_xent(const void* logits, int dtype, int64_t rows, int32_t V, const int64_t* targets, float* loss,
+             void* d_logits, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * optimize(): clip_grad_norm_ + Adam (src/training.py:194-199, :24-26) over a flat f32 parameter arena.
+ * step_count: device int64 (incremented here); norm_out: device f32 (pre-clip global L2 norm);
+ * partials: device f32 scratch [gic_clip_adam_partials(n)].
+ */
+int64_t gic_clip_adam_partials(int64_t n);
+int gic_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, float clip_norm, int64_t* step_count, float* norm_out,
+                  float* partials, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GICAP_H_ */

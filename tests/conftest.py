@@ -15,3 +15,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """hipcc cross-compiles gfx950 without a GPU; no-op when libgicap.so is up to date."""
+    import importlib
+    build = importlib.import_module("gan_image_captioning_amd.build")
+    build.build()

@@ -1,0 +1,43 @@
+"""Shared helpers of the GPU parity tests (oracle <-> HIP library)."""
+import torch
+
+from oracle import cpu_step as O
+
+
+def dec_param_names(nl):
+    names = ["decoder.embed.weight"]
+    for l in range(nl):
+        names += [f"decoder.lstm.weight_ih_l{l}", f"decoder.lstm.weight_hh_l{l}",
+                  f"decoder.lstm.bias_ih_l{l}", f"decoder.lstm.bias_hh_l{l}"]
+    return names + ["decoder.linear.weight", "decoder.linear.bias"]
+
+
+def disc_param_names(nconv):
+    names = ["embeddings.weight"]
+    for k in range(nconv):
+        names += [f"convs.{k}.weight", f"convs.{k}.bias"]
+    return names + ["highway.weight", "highway.bias", "feature2out.weight", "feature2out.bias",
+                    "out2logits.weight", "out2logits.bias"]
+
+
+def dec_params(gp, dev):
+    nl = O.num_lstm_layers(gp)
+    return [gp[n].to(dev).contiguous() for n in dec_param_names(nl)]
+
+
+def disc_params(dp, dev):
+    return [dp[n].to(dev).contiguous() for n in disc_param_names(O.disc_num_convs(dp))]
+
+
+def close(got, want, rtol, atol_scale=1e-5, what=""):
+    """assert_close with an absolute floor relative to the reference tensor's largest entry."""
+    got = got.detach().double().cpu()
+    want = want.detach().double().cpu()
+    scale = float(want.abs().max()) if want.numel() else 0.0
+    torch.testing.assert_close(got, want, rtol=rtol, atol=atol_scale * scale + 1e-30, msg=lambda s: f"{what}: {s}")
+
+
+def rel_l2(got, want):
+    got = got.detach().double().cpu().reshape(-1)
+    want = want.detach().double().cpu().reshape(-1)
+    return float((got - want).norm() / (want.norm() + 1e-30))

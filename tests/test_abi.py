@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: libgicap.so loads and exports every symbol that
+include/gicap.h declares; argument validation returns status codes (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gicap.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gic_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_bound_symbols():
+    from gan_image_captioning_amd import _lib
+    assert set(declared_symbols()) == set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    from gan_image_captioning_amd import _lib
+    lib = ctypes.CDLL(_lib.library_path())
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"libgicap.so does not export {name}"
+    assert _lib.load().gic_abi_version() == 1
+
+
+def test_argument_validation_returns_status_not_crash():
+    from gan_image_captioning_amd import _lib
+    lib = _lib.load()
+    assert lib.gic_gemm(None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, None, 0, 1.0, None) == -1
+    assert b"null operand" in lib.gic_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(lib.gic_gan_losses(99, None, None, None, 0, None, None, None, None, None, None, None), "gan_losses")
+    d = _lib.DecoderDims(4, 5, 50, 8, 16, 9, 0)          # NL out of range
+    assert lib.gic_decoder_prepare(ctypes.byref(d), None, None, None) == -1
+    assert b"gen_num_layers" in lib.gic_last_error()
+
+
+def test_struct_layouts_match_header_sizes():
+    """ctypes mirrors of the C structs: pointer arrays sized by GIC_MAX_LAYERS / GIC_MAX_CONVS."""
+    from gan_image_captioning_amd import _lib
+    P = ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_lib.DecoderDims) == 7 * 4
+    assert ctypes.sizeof(_lib.DecoderParams) == (3 + 4 * _lib.MAX_LAYERS) * P
+    assert ctypes.sizeof(_lib.DecoderGrads) == (4 + 4 * _lib.MAX_LAYERS) * P
+    assert ctypes.sizeof(_lib.DecoderState) == (3 + 3 * _lib.MAX_LAYERS) * P
+    assert ctypes.sizeof(_lib.DiscDims) == (6 + 2 * _lib.MAX_CONVS + 3) * 4
+    assert ctypes.sizeof(_lib.DiscParams) == (7 + 2 * _lib.MAX_CONVS) * P
+
+
+def test_cpu_tensors_are_refused():
+    import torch
+    from gan_image_captioning_amd import engine
+    from gan_image_captioning_amd._lib import GicError
+    with pytest.raises(GicError):
+        engine.embedding_fwd(torch.zeros(4, 4), torch.zeros(2, dtype=torch.long))
