@@ -99,8 +99,8 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     "gic_xent": (C.c_int, [c_void_p, C.c_int, C.c_int64, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gic_clip_adam_partials": (C.c_int64, [C.c_int64]),
-    "gic_clip_adam": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
-                                C.c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gic_clip_adam": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                C.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -113,8 +113,8 @@ __global__ __launch_bounds__(kNormBlock) void sqnorm_partial_kernel(const float*
 }
 
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                         float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                         float clip_norm, const int64_t* __restrict__ step_count,
+                                                         float* __restrict__ v, long n, double lr_d, double b1_d, double b2_d, double eps_d,
+                                                         double clip_d, const int64_t* __restrict__ step_count,
                                                          const float* __restrict__ partials, int nparts, float* __restrict__ norm_out) {
   __shared__ float red[16];
   // every block re-reduces the (few) partials in the same order -> identical clip coefficient everywhere
@@ -123,16 +123,17 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
   s = block_sum(s, red);
   const float norm = sqrtf(s);
   if (blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = norm;
-  float coef = clip_norm / (norm + 1e-6f);           // torch.nn.utils.clip_grad_norm_
+  float coef = (float)clip_d / (norm + 1e-6f);       // torch.nn.utils.clip_grad_norm_
   coef = coef > 1.f ? 1.f : coef;
+  // scalar hyper-parameter arithmetic in float64, like torch.optim.Adam's Python scalars
   const double t = (double)step_count[0];
-  const float bc1 = (float)(1.0 - pow((double)b1, t));
-  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
-  const float step_size = lr / bc1;
+  const float omb1 = (float)(1.0 - b1_d), omb2 = (float)(1.0 - b2_d), b2 = (float)b2_d, eps = (float)eps_d;
+  const float bc2_sqrt = (float)sqrt(1.0 - pow(b2_d, t));
+  const float step_size = (float)(lr_d / (1.0 - pow(b1_d, t)));
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gi = g[i] * coef;
-    const float mi = m[i] + (gi - m[i]) * (1.f - b1);        // exp_avg.lerp_(grad, 1-beta1)
-    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    const float mi = m[i] + (gi - m[i]) * omb1;              // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * b2 + omb2 * gi * gi;             // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = p[i] - step_size * (mi / denom);
@@ -175,8 +176,8 @@ int gic_xent(const void* logits, int dtype, int64_t rows, int32_t V, const int64
 
 int64_t gic_clip_adam_partials(int64_t n) { return (n + kNormElemsPerBlock - 1) / kNormElemsPerBlock; }
 
-int gic_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                  float beta2, float eps, float clip_norm, int64_t* step_count, float* norm_out, float* partials, void* stream_) {
+int gic_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                  double beta2, double eps, double clip_norm, int64_t* step_count, float* norm_out, float* partials, void* stream_) {
   GIC_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && step_count && norm_out && partials, "clip_adam: null pointer");
   GIC_CHECK_ARG(n > 0, "clip_adam: n<=0");
   hipStream_t stream = (hipStream_t)stream_;

@@ -1,0 +1,133 @@
+"""The adversarial G+D train step as one direct kernel sequence (no autograd engine).
+
+Same math and the same step order as ``GANInstructor._adv_step_autograd`` / SURVEY.md §8(c) -- body
+of reference src/training.py:136-183 with both backward passes on pre-update weights, then both
+optimizer steps -- but every buffer is allocated once per (batch, length) and gradients are written
+straight into the flat arenas that the optimizer kernels and the RCCL all-reduce read.
+
+Work that the reference executes and discards is skipped (results identical):
+  * D's parameter gradients from g_loss (zeroed by the next zero_grad, training.py:195);
+  * D(real) is evaluated on token ids (gather) rather than a dense one-hot (training.py:158), unless
+    ``real_as_ids=0``;
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import engine
+from .generator import SEEDS
+
+
+class FusedAdvStep:
+    def __init__(self, gen, disc, gen_arena, disc_arena, args, reducer=None):
+        self.gen, self.disc, self.args = gen, disc, args
+        self.gen_arena, self.disc_arena = gen_arena, disc_arena
+        self.reducer = reducer
+        self.cgan = int(args.conditional_gan) == 1
+        self.dec = gen.decoder.engine()
+        self.den = disc.engine()
+        self._buf: Dict[tuple, dict] = {}
+        self._gen_grads = None
+        self._disc_grads = None
+
+    # grads of the decoder parameters are views into the generator arena (order = Decoder.param_list())
+    def _grad_lists(self):
+        if self._gen_grads is None:
+            by_param = {id(p): g for p, g in zip(self.gen_arena.params, self.gen_arena.grad_views())}
+            self._gen_grads = [by_param[id(p)] for p in self.gen.decoder.param_list()]
+            by_param = {id(p): g for p, g in zip(self.disc_arena.params, self.disc_arena.grad_views())}
+            self._disc_grads = [by_param[id(p)] for p in self.disc.param_list()]
+        return self._gen_grads, self._disc_grads
+
+    def _buffers(self, B: int, L: int, dev) -> dict:
+        key = (B, L)
+        if key not in self._buf:
+            dec, den = self.dec, self.den
+            self._buf[key] = {
+                "dec_state": dec.alloc_state(B, L, dev),
+                "dec_ws": dec.alloc_bwd_ws(B, L, dev),
+                "probs": torch.empty(B, L, dec.V, device=dev, dtype=dec.act),
+                "ids": torch.empty(B, L, device=dev, dtype=torch.int64),
+                "d_feat": torch.empty(B, dec.E, device=dev, dtype=torch.float32),
+                "d_probs": torch.empty(B, L, dec.V, device=dev, dtype=dec.act),
+                "st_real": den.alloc_state(B, L, dev), "st_fake": den.alloc_state(B, L, dev), "st_gen": den.alloc_state(B, L, dev),
+                "disc_ws": den.alloc_bwd_ws(B, L, dev),
+                "logits": torch.empty(3, B * den.R, device=dev, dtype=torch.float32),
+                "ones": torch.ones(B, device=dev, dtype=torch.int64),
+            }
+        return self._buf[key]
+
+    def __call__(self, images, captions, max_caption_len: int, train: bool = True, noise_u=None, keep_masks=None,
+                 opt_step: bool = True) -> dict:
+        """One step.  Returns device tensors: losses [g_loss, d_loss], ids, probs, logits (real, fake, gen).
+        ``noise_u`` [L,B,V] / ``keep_masks`` (3 x [B*R,F]) make the step deterministic for parity runs."""
+        a = self.args
+        gen, disc = self.gen, self.disc
+        B, L = captions.shape[0], int(max_caption_len)
+        dev = captions.device
+        engine.require_gpu(captions, images)
+        buf = self._buffers(B, L, dev)
+        gparams = [p.detach() for p in gen.decoder.param_list()]
+        dparams = [p.detach() for p in disc.param_list()]
+        g_grads, d_grads = self._grad_lists()
+        T = float(gen.decoder.temperature)
+        d_train = bool(train)            # dropout active in train mode only (disc.train()/eval(), training.py:215,219)
+
+        # ---- features (training.py:144-147)
+        if self.cgan:
+            feats = gen.encoder.forward_fused(images, train)
+        else:
+            feats = engine.embedding_fwd(gparams[0], buf["ones"])
+        # ---- one roll-out (training.py:150)
+        seed = 0 if noise_u is not None else SEEDS.next()
+        probs, ids, dst = self.dec.sample_fwd(gparams, feats, L, T, False, noise_u, seed, state=buf["dec_state"],
+                                              out=buf["probs"], ids=buf["ids"])
+        # ---- three discriminator evaluations (training.py:162-164)
+        km = keep_masks if keep_masks is not None else (None, None, None)
+        seeds = [0 if km[i] is not None else SEEDS.next() for i in range(3)]
+        if int(getattr(a, "real_as_ids", 1)):
+            real_soft, real_ids = None, captions
+        else:
+            real_soft = self.den.soft_input(torch.nn.functional.one_hot(captions, self.den.V).float())
+            real_ids = None
+        lg = buf["logits"]
+        self.den.fwd(dparams, real_soft, real_ids, d_train, km[0], seeds[0], state=buf["st_real"], logits=lg[0])
+        self.den.fwd(dparams, probs, None, d_train, km[1], seeds[1], state=buf["st_fake"], logits=lg[1])
+        self.den.fwd(dparams, probs, None, d_train, km[2], seeds[2], state=buf["st_gen"], logits=lg[2])
+        losses, lgrads = engine.gan_losses(a.adv_loss_type, lg[0], lg[1], lg[2], want_grads=train)
+        out = {"losses": losses, "ids": ids, "probs": probs, "logits": lg}
+        if not train:
+            return out
+
+        # ---- D backward: d_loss -> D parameters (training.py:168 minus the step)
+        self.den.bwd(dparams, buf["st_real"], real_soft, real_ids, d_train, lgrads["dd_real"], True, False,
+                     grads=d_grads, accumulate=False, ws=buf["disc_ws"])
+        self.den.bwd(dparams, buf["st_fake"], probs, None, d_train, lgrads["dd_fake"], True, False,
+                     grads=d_grads, accumulate=True, ws=buf["disc_ws"])
+        if self.reducer is not None:
+            self.reducer.start(self.disc_arena.grad)           # overlaps with the generator backward below
+        # ---- G backward: g_loss -> D(gen) input grad -> decoder (training.py:169 minus the step)
+        if a.adv_loss_type == "rsgan":
+            self.gen_arena.grad.zero_()                        # utils.py:48: g_loss has no path to G
+        else:
+            self.den.bwd(dparams, buf["st_gen"], probs, None, d_train, lgrads["dg_out"], False, True,
+                         ws=buf["disc_ws"], d_inp=buf["d_probs"])
+            self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"],
+                                grads=g_grads + [buf["d_feat"]])
+            if self.cgan:
+                gen.encoder.backward_fused(buf["d_feat"])
+            else:   # features = embed(<S>) broadcast: fold d_features into row 1 of the embedding gradient
+                engine.embedding_bwd(buf["d_feat"], buf["ones"], self.dec.V, d_weight=g_grads[0], zero_first=False)
+        if self.reducer is not None:
+            self.reducer.start(self.gen_arena.grad)
+            self.reducer.wait_all()
+        if opt_step:
+            self.disc_opt.step()
+            self.gen_opt.step()
+        return out
+
+    def bind_optimizers(self, gen_opt, disc_opt) -> "FusedAdvStep":
+        self.gen_opt, self.disc_opt = gen_opt, disc_opt
+        return self

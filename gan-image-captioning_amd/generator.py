@@ -1,0 +1,234 @@
+"""Generator: Encoder / Decoder / Generator with the reference's module API
+(src/generator.py:8-123) and state-dict key names, computing through libgicap.so.
+
+Differences a caller can observe (all documented in DESIGN.md):
+  * ``Decoder.sample`` returns its probabilities in the compute dtype (bf16 when
+    ``--compute-dtype bf16``; float32 in parity mode), laid out [B, L, V] contiguous.
+  * ``sample`` / ``Discriminator.forward`` take optional explicit noise (``noise_u``,
+    ``keep_mask``) so a run can be replayed bit-for-bit against the CPU reference; without it
+    noise comes from an on-device Philox stream seeded from ``torch.initial_seed()``.
+  * ``Generator.forward`` reads ``args.conditional_gan`` (the reference reads a non-existent
+    ``args.cgan``, generator.py:109, and is never called by training.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import engine
+from .trunk import ResNetTrunk, encoder_head_bwd, encoder_head_fwd
+
+
+def _compute_dtype(args) -> int:
+    return engine.parse_dtype(getattr(args, "compute_dtype", "bf16"))
+
+
+class _SeedStream:
+    """Host-side counter that hands a fresh Philox seed to every stochastic kernel launch."""
+
+    def __init__(self):
+        self._n = 0
+
+    def next(self) -> int:
+        self._n += 1
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._n * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+
+
+SEEDS = _SeedStream()
+
+
+# ------------------------------------------------------------------------------------------ embedding
+class _EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, ids):
+        ctx.save_for_backward(ids)
+        ctx.vocab = weight.shape[0]
+        return engine.embedding_fwd(weight.detach(), ids)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (ids,) = ctx.saved_tensors
+        return engine.embedding_bwd(d_out, ids, ctx.vocab), None
+
+
+class Embedding(nn.Module):
+    """nn.Embedding(V, E) stand-in (same parameter name / init) used as a callable (training.py:68,147)."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int):
+        super().__init__()
+        self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
+        self.weight = nn.Parameter(torch.empty(num_embeddings, embedding_dim))
+        nn.init.normal_(self.weight)
+
+    def forward(self, ids):
+        return _EmbeddingFn.apply(self.weight, ids)
+
+
+class _LSTMParams(nn.Module):
+    """Parameter container with nn.LSTM's names, shapes and default init (generator.py:32)."""
+
+    def __init__(self, input_size: int, hidden_size: int, num_layers: int):
+        super().__init__()
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        k = 1.0 / math.sqrt(hidden_size)
+        for l in range(num_layers):
+            din = input_size if l == 0 else hidden_size
+            for name, shape in ((f"weight_ih_l{l}", (4 * hidden_size, din)), (f"weight_hh_l{l}", (4 * hidden_size, hidden_size)),
+                                (f"bias_ih_l{l}", (4 * hidden_size,)), (f"bias_hh_l{l}", (4 * hidden_size,))):
+                self.register_parameter(name, nn.Parameter(torch.empty(shape).uniform_(-k, k)))
+
+    def layer_params(self, l: int) -> List[nn.Parameter]:
+        return [getattr(self, f"{n}_l{l}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+
+
+class _LinearParams(nn.Module):
+    """Parameter container with nn.Linear's names, shapes and default init."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        k = 1.0 / math.sqrt(in_features)
+        self.weight = nn.Parameter(torch.empty(out_features, in_features).uniform_(-k, k))
+        self.bias = nn.Parameter(torch.empty(out_features).uniform_(-k, k)) if bias else None
+
+
+# ------------------------------------------------------------------------------------------ decoder
+class _SampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, temperature, pretrain, max_len, noise_u, seed, features, *params):
+        dparams = [p.detach() for p in params]
+        out, ids, st = eng.sample_fwd(dparams, features.detach().float(), max_len, temperature, pretrain, noise_u, seed)
+        ctx.eng, ctx.temperature, ctx.pretrain = eng, temperature, pretrain
+        ctx.st, ctx.dparams = st, dparams
+        ctx.save_for_backward(out, ids)
+        ctx.mark_non_differentiable(ids)
+        return out, ids
+
+    @staticmethod
+    def backward(ctx, d_out, _d_ids):
+        out, ids = ctx.saved_tensors
+        grads = ctx.eng.sample_bwd(ctx.dparams, ctx.st, out, ids, d_out, ctx.temperature, ctx.pretrain)
+        ctx.st = None
+        return (None, None, None, None, None, None, grads[-1], *grads[:-1])
+
+
+class Decoder(nn.Module):
+    """Embedding + LSTM + Linear caption decoder (generator.py:27-96)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.embed = Embedding(args.vocab_size, args.gen_embed_dim)
+        self.lstm = _LSTMParams(args.gen_embed_dim, args.gen_hidden_dim, args.gen_num_layers)
+        self.linear = _LinearParams(args.gen_hidden_dim, args.vocab_size)
+        self.max_seq_length = args.max_seq_len
+        self.temperature = args.temperature          # mutated from outside (training.py:191)
+        self.args = args
+        self._engine: Optional[engine.DecoderEngine] = None
+
+    def engine(self) -> engine.DecoderEngine:
+        if self._engine is None:
+            a = self.args
+            self._engine = engine.DecoderEngine(a.vocab_size, a.gen_embed_dim, a.gen_hidden_dim, a.gen_num_layers, _compute_dtype(a))
+        return self._engine
+
+    def param_list(self) -> List[nn.Parameter]:
+        ps = [self.embed.weight]
+        for l in range(self.lstm.num_layers):
+            ps += self.lstm.layer_params(l)
+        return ps + [self.linear.weight, self.linear.bias]
+
+    def sample(self, features, states=None, pretrain=False, max_caption_len=34, noise_u=None):
+        """Greedy Gumbel-softmax roll-out (generator.py:55-81): returns (outputs [B,L,V], ids int64 [B,L]).
+        Gradients flow through ``outputs`` to the decoder parameters and ``features``; never through ``ids``."""
+        if states is not None:
+            raise NotImplementedError("sample(states=...) is not supported: training.py never passes initial states")
+        seed = 0 if noise_u is not None else SEEDS.next()
+        return _SampleFn.apply(self.engine(), float(self.temperature), bool(pretrain), int(max_caption_len), noise_u, seed,
+                               features, *self.param_list())
+
+    def forward(self, features, caps, lengths, pretrain=False):
+        """Teacher-forced decode (generator.py:39-53).  Dead on the training path of the reference (never
+        called by training.py); kept for API completeness and not accelerated."""
+        raise NotImplementedError("Decoder.forward (teacher forcing) is not on the hot path; use sample()")
+
+    def add_gumbel(self, o_t, eps=1e-10, gpu=0):
+        """o_t + Gumbel(0,1) noise (generator.py:84-96); on the hot path this is fused into sample()."""
+        u = torch.empty_like(o_t, dtype=torch.float32).uniform_(0, 1)
+        return o_t + (-torch.log(-torch.log(u + eps) + eps))
+
+
+# ------------------------------------------------------------------------------------------ encoder
+class _EncoderHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dtype, training, momentum, eps, trunk_feat, weight, bias, gamma, beta, running_mean, running_var):
+        out, saved = encoder_head_fwd(dtype, trunk_feat.detach(), weight.detach(), bias.detach(), gamma.detach(), beta.detach(),
+                                      running_mean, running_var, training, momentum, eps)
+        ctx.saved, ctx.dtype = saved, dtype
+        ctx.w = weight.detach()
+        ctx.gamma = gamma.detach()
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        dw, db, dgamma, dbeta = encoder_head_bwd(ctx.dtype, ctx.saved, ctx.w, ctx.gamma, d_out.contiguous())
+        return None, None, None, None, None, dw, db, dgamma, dbeta, None, None
+
+
+class _BatchNorm1dParams(nn.Module):
+    def __init__(self, num_features: int, momentum: float):
+        super().__init__()
+        self.num_features, self.momentum, self.eps = num_features, momentum, 1e-5
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class Encoder(nn.Module):
+    """ResNet trunk (frozen, forward only) -> Linear -> BatchNorm1d(momentum=0.01) (generator.py:8-25)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.resnet = ResNetTrunk(getattr(args, "encoder_arch", "resnet18"))
+        self.linear = _LinearParams(self.resnet.out_features, args.gen_embed_dim)
+        self.bn = _BatchNorm1dParams(args.gen_embed_dim, momentum=0.01)
+        self.args = args
+
+    def forward(self, images):
+        with torch.no_grad():                                        # generator.py:21-22
+            feats = self.resnet(images, _compute_dtype(self.args))
+        feats = feats.reshape(feats.size(0), -1)
+        if self.training:
+            self.bn.num_batches_tracked += 1
+        return _EncoderHeadFn.apply(_compute_dtype(self.args), self.training, self.bn.momentum, self.bn.eps, feats,
+                                    self.linear.weight, self.linear.bias, self.bn.weight, self.bn.bias,
+                                    self.bn.running_mean, self.bn.running_var)
+
+
+class Generator(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.encoder = Encoder(args)
+        self.decoder = Decoder(args)
+        self.args = args
+        self.init_params()
+
+    def forward(self, images, caps, lengths, pretrain=False):
+        if self.args.conditional_gan:
+            features = self.encoder(images)
+        else:
+            features = self.decoder.embed(torch.ones(len(images), dtype=torch.long, device=images.device))
+        return self.decoder(features, caps, lengths, pretrain)
+
+    def init_params(self):
+        """generator.py:116-123: every parameter with >= 1 dim (biases, BN affine and trunk convs included)."""
+        for param in self.parameters():
+            if param.requires_grad and len(param.shape) > 0:
+                if self.args.gen_init == "uniform":
+                    torch.nn.init.uniform_(param, a=-0.05, b=0.05)
+                elif self.args.gen_init == "normal":
+                    torch.nn.init.normal_(param, std=1 / math.sqrt(param.shape[0]))

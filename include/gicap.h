@@ -215,18 +215,20 @@ int gic_gan_losses(int loss_type, const float* d_real, const float* d_fake, cons
                    float* losses, float* dd_real, float* dd_fake, float* dg_out, float* dg_real, float* dg_fake,
                    void* stream);
 
-/* CrossEntropyLoss over all rows (training.py:81-83): loss (device scalar) and d_logits = (softmax - onehot)/rows. */
+/* CrossEntropyLoss over all rows (training.py:81-83): loss = device f32[1+rows] (loss[0] = mean, rest = per-row
+ * scratch) and d_logits = (softmax - onehot)/rows (optional). */
 int gic_xent(const void* logits, int dtype, int64_t rows, int32_t V, const int64_t* targets, float* loss,
              void* d_logits, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * optimize(): clip_grad_norm_ + Adam (src/training.py:194-199, :24-26) over a flat f32 parameter arena.
  * step_count: device int64 (incremented here); norm_out: device f32 (pre-clip global L2 norm);
- * partials: device f32 scratch [gic_clip_adam_partials(n)].
+ * partials: device f32 scratch [gic_clip_adam_partials(n)].  Hyper-parameters are doubles: torch.optim.Adam forms
+ * 1-beta, lr/(1-beta1^t) and sqrt(1-beta2^t) in Python float64 before touching f32 tensors, and so does the kernel.
  */
 int64_t gic_clip_adam_partials(int64_t n);
-int gic_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                  float beta1, float beta2, float eps, float clip_norm, int64_t* step_count, float* norm_out,
+int gic_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                  double beta1, double beta2, double eps, double clip_norm, int64_t* step_count, float* norm_out,
                   float* partials, void* stream);
 
 #ifdef __cplusplus

@@ -51,5 +51,7 @@ def initial_params(g):
     gp = O.make_gen_params(m["V"], m["E"], m["H"], m["NL"], pg, trunk_feat_dim=m.get("trunk_feat_dim"))
     dp = O.make_disc_params(m["V"], pg, embed_dim=m["De"], num_rep=m["R"], filter_sizes=m["fs"], num_filters=m["nf"])
     for k, v in {**gp, **dp}.items():
-        torch.testing.assert_close(summarize(v), g.t("p0sum/" + k), rtol=0, atol=0)
+        got, want = summarize(v), g.t("p0sum/" + k)
+        torch.testing.assert_close(got[3:], want[3:], rtol=0, atol=0)          # strided sample: bit-exact
+        torch.testing.assert_close(got[:3], want[:3], rtol=1e-10, atol=0)      # fp64 sums: thread-count dependent order
     return gp, dp

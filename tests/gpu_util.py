@@ -37,6 +37,20 @@ def close(got, want, rtol, atol_scale=1e-5, what=""):
     torch.testing.assert_close(got, want, rtol=rtol, atol=atol_scale * scale + 1e-30, msg=lambda s: f"{what}: {s}")
 
 
+def close_mostly(got, want, rtol, atol_scale, what, max_outlier_frac=5e-3, max_rel_l2=2e-3):
+    """For tensors downstream of a discontinuous op (max-over-time argmax, relu gate): a near-tie
+    resolved differently in fp32 re-routes one contribution, so allow a small fraction of entries
+    outside the element-wise tolerance while bounding the relative L2 error of the whole tensor."""
+    g = got.detach().double().cpu()
+    w = want.detach().double().cpu()
+    scale = float(w.abs().max()) if w.numel() else 0.0
+    bad = (g - w).abs() > (atol_scale * scale + rtol * w.abs())
+    frac = float(bad.double().mean()) if w.numel() else 0.0
+    err = rel_l2(g, w)
+    assert frac <= max_outlier_frac and err <= max_rel_l2, f"{what}: {frac:.2%} entries out of tolerance, rel L2 {err:.2e}"
+    return frac, err
+
+
 def rel_l2(got, want):
     got = got.detach().double().cpu().reshape(-1)
     want = want.detach().double().cpu().reshape(-1)

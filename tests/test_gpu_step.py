@@ -1,0 +1,198 @@
+"""End-to-end parity of the adversarial train step on the GPU against the golden vectors produced by
+the reference's own classes (tests/golden/, oracle/make_golden.py): GANInstructor through BOTH step
+drivers (``fused`` kernel sequence and ``autograd`` module API), fp32 parity mode, explicit noise.
+
+Per step (parameters teacher-forced to the reference's trajectory, like tests/test_oracle_golden.py):
+token ids exact; probabilities / logits rtol 1e-4; losses rel 1e-5; gradient norms rel 1e-4; raw
+gradients rtol 2e-3 (+1e-4 x max entry); optimizer: clip+Adam from the golden gradients reproduces the
+reference's post-step weights to 1e-6 (tests/test_gpu_kernels.py) and end-to-end stays within lr.
+"""
+import pytest
+import torch
+
+from tests.golden_io import Golden, initial_params
+from tests.gpu_util import close, close_mostly, dec_param_names, disc_param_names
+
+pytestmark = pytest.mark.gpu
+
+
+def make_instructor(m, impl, dtype="fp32", real_as_ids=1):
+    from gan_image_captioning_amd.args import default_args
+    from gan_image_captioning_amd.training import GANInstructor
+    args = default_args(vocab_size=m["V"], gen_embed_dim=m["E"], gen_hidden_dim=m["H"], gen_num_layers=m["NL"],
+                        disc_embed_dim=m["De"], disc_num_rep=m["R"], disc_filter_sizes=m["fs"], disc_num_filters=m["nf"],
+                        adv_loss_type=m["loss"], clip_norm=m["clip"], gen_lr=m["gen_lr"], disc_lr=m["disc_lr"],
+                        temperature=m["T0"], temp_adpt=m["adapt"], adv_epochs=m["adv_epochs"], compute_dtype=dtype,
+                        step_impl=impl, real_as_ids=real_as_ids, device="cuda", log_file=None, model_dir=None, save_dir=None)
+    return GANInstructor(args, None, None), args
+
+
+def load_params(inst, gp, dp):
+    with torch.no_grad():
+        for n, p in zip(dec_param_names(inst.args.gen_num_layers), inst.gen.decoder.param_list()):
+            p.copy_(gp[n])
+        for n, p in zip(disc_param_names(len(inst.args.disc_num_filters)), inst.disc.param_list()):
+            p.copy_(dp[n])
+
+
+@pytest.mark.parametrize("impl", ["fused", "autograd"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_scaled", "tiny_rep2", "tiny_rsgan", "cfg1"])
+def test_adv_step_matches_reference(name, impl):
+    g = Golden(name)
+    m = g.meta
+    inst, args = make_instructor(m, impl)
+    dev = args.device
+    gp, dp = initial_params(g)
+    caps = g.t("caps").to(dev)
+    gnames, dnames = dec_param_names(m["NL"]), disc_param_names(len(m["nf"]))
+    inst.gen.train()
+    inst.disc.train()
+    for step in range(m["steps"]):
+        load_params(inst, gp, dp)                      # teacher-forced trajectory
+        inst.gen.decoder.temperature = m["temperatures"][step]
+        u = g.t(f"s{step}/u").to(dev)
+        masks = [mk.to(dev) for mk in g.masks(step)]
+        pre = f"s{step}/"
+        if impl == "fused":
+            out = inst.fused(None, caps, m["L"], True, u, masks, opt_step=False)
+            losses, ids, probs, lg = out["losses"], out["ids"], out["probs"], out["logits"]
+            torch.cuda.synchronize()
+            assert torch.equal(ids.cpu(), g.t(pre + "ids")), "token ids differ from the reference"
+            close(probs, g.t(pre + "probs"), rtol=1e-4, atol_scale=1e-6, what="probs")
+            for i, k in enumerate(("d_real", "d_fake", "g_out")):
+                close(lg[i], g.t(pre + k), rtol=1e-4, atol_scale=1e-5, what=k)
+        else:
+            # module-API flow; stop before the optimizer by running the pieces of _adv_step_autograd
+            losses = _autograd_backward_only(inst, caps, m["L"], u, masks)
+            torch.cuda.synchronize()
+        assert float(losses[0]) == pytest.approx(float(g.t(pre + "g_loss")), rel=1e-5)
+        assert float(losses[1]) == pytest.approx(float(g.t(pre + "d_loss")), rel=1e-5)
+        # raw gradients in the flat arenas
+        full = m["full"]
+        want = g.group(pre + "grad/")
+        got = {n: p.grad for n, p in zip(gnames, inst.gen.decoder.param_list())}
+        got.update({n: p.grad for n, p in zip(dnames, inst.disc.param_list())})
+        dn = float(torch.sqrt(sum((got[n].double() ** 2).sum() for n in dnames)))
+        gn = float(torch.sqrt(sum((got[n].double() ** 2).sum() for n in gnames)))
+        assert dn == pytest.approx(float(g.t(pre + "d_norm")), rel=1e-4)
+        # At T=100 the softmax is saturated and G's gradient is numerically nil (norm ~1e-11, made of
+        # e^-100-sized terms): only its insignificance is comparable across exp/log implementations.
+        g_nil = float(g.t(pre + "g_norm")) < 1e-8
+        if g_nil:
+            assert gn < 1e-8
+        else:
+            assert gn == pytest.approx(float(g.t(pre + "g_norm")), rel=2e-3)
+        if full:
+            upstream_of_pool = set(dnames[:1 + 2 * len(m["nf"])])
+            for n, w in want.items():
+                if n in gnames and g_nil:
+                    continue
+                if n in upstream_of_pool or n in gnames:      # may carry a re-routed max-pool near-tie
+                    close_mostly(got[n], w, 2e-3, 1e-4, n, 1e-2, 1.5e-2)
+                else:
+                    close(got[n], w, rtol=2e-3, atol_scale=1e-4, what=n)
+            if m["loss"] == "rsgan":
+                assert set(want) == set(dnames)               # no generator gradient at all (utils.py:48)
+                assert gn == 0.0
+        # optimizer step from our own gradients stays within lr of the reference's post-step weights
+        inst.disc_opt.step()
+        inst.gen_opt.step()
+        torch.cuda.synchronize()
+        if full:
+            post = g.group(pre + "post/")
+            for n, p in list(zip(gnames, inst.gen.decoder.param_list())) + list(zip(dnames, inst.disc.param_list())):
+                lr = m["gen_lr"] if n in gnames else m["disc_lr"]
+                assert float((p.detach().cpu() - post[n]).abs().max()) <= 1.05 * lr, n
+            gp = {n: post[n] for n in gnames}
+            dp = {n: post[n] for n in dnames}
+        else:
+            gp = {n: p.detach().cpu().clone() for n, p in zip(gnames, inst.gen.decoder.param_list())}
+            dp = {n: p.detach().cpu().clone() for n, p in zip(dnames, inst.disc.param_list())}
+            if step > 0:
+                break        # own trajectory beyond step 0 is only loosely comparable (see test_oracle_golden)
+
+
+def _autograd_backward_only(inst, caps, L, u, masks):
+    from gan_image_captioning_amd.utils import get_losses
+    features = inst._features(None, caps.shape[0])
+    gen_captions, _ = inst.gen.decoder.sample(features, max_caption_len=L, noise_u=u)
+    d_real = inst.disc(caps, keep_mask=masks[0])
+    d_fake = inst.disc(gen_captions.detach(), keep_mask=masks[1])
+    with inst.disc.input_grad_only():
+        g_out = inst.disc(gen_captions, keep_mask=masks[2])
+    g_loss, d_loss = get_losses(d_real, d_fake, g_out, inst.args.adv_loss_type, detach_d_for_g=True)
+    inst.disc_opt.zero_grad()
+    inst.gen_opt.zero_grad()
+    d_loss.backward()
+    if g_loss.requires_grad:
+        g_loss.backward()
+    return torch.stack([g_loss.detach(), d_loss.detach()])
+
+
+def test_dense_one_hot_real_path_equals_ids_path():
+    g = Golden("tiny")
+    m = g.meta
+    gp, dp = initial_params(g)
+    res = []
+    for real_as_ids in (1, 0):
+        inst, args = make_instructor(m, "fused", real_as_ids=real_as_ids)
+        load_params(inst, gp, dp)
+        inst.gen.decoder.temperature = m["temperatures"][0]
+        out = inst.fused(None, g.t("caps").to(args.device), m["L"], True, g.t("s0/u").to(args.device),
+                         [mk.to(args.device) for mk in g.masks(0)], opt_step=False)
+        torch.cuda.synchronize()
+        res.append((out["losses"].cpu(), inst.disc_arena.grad.cpu().clone()))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-6, atol=0)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-4, atol=1e-8)
+
+
+def test_eval_mode_step_matches_reference():
+    g = Golden("tiny_eval")
+    m = g.meta
+    inst, args = make_instructor(m, "fused")
+    gp, dp = initial_params(g)
+    load_params(inst, gp, dp)
+    inst.gen.eval()
+    inst.disc.eval()
+    inst.gen.decoder.temperature = m["temperatures"][0]
+    out = inst.fused(None, g.t("caps").to(args.device), m["L"], False, g.t("s0/u").to(args.device), None)
+    torch.cuda.synchronize()
+    assert torch.equal(out["ids"].cpu(), g.t("s0/ids"))
+    assert float(out["losses"][0]) == pytest.approx(float(g.t("s0/g_loss")), rel=1e-5)
+    assert float(out["losses"][1]) == pytest.approx(float(g.t("s0/d_loss")), rel=1e-5)
+
+
+def test_bf16_step_close_to_reference():
+    """bf16 compute mode on the cfg1 fixture: loss rel error <= 2e-2; id match-rate reported."""
+    g = Golden("cfg1")
+    m = g.meta
+    inst, args = make_instructor(m, "fused", dtype="bf16")
+    gp, dp = initial_params(g)
+    load_params(inst, gp, dp)
+    inst.gen.decoder.temperature = m["temperatures"][0]
+    out = inst.fused(None, g.t("caps").to(args.device), m["L"], True, g.t("s0/u").to(args.device),
+                     [mk.to(args.device) for mk in g.masks(0)])
+    torch.cuda.synchronize()
+    match = float((out["ids"].cpu() == g.t("s0/ids")).float().mean())
+    print(f"bf16 id match-rate vs reference: {match:.3f}")
+    assert match >= 0.95
+    assert float(out["losses"][0]) == pytest.approx(float(g.t("s0/g_loss")), rel=2e-2)
+    assert float(out["losses"][1]) == pytest.approx(float(g.t("s0/d_loss")), rel=2e-2)
+
+
+def test_multi_step_training_runs_and_updates(tmp_path):
+    """A few free-running steps with on-device Philox noise through adv_step (the path bench.py times)."""
+    g = Golden("cfg1")
+    m = g.meta
+    inst, args = make_instructor(m, "fused", dtype="bf16")
+    caps = g.t("caps").to(args.device)
+    before = inst.gen_arena.flat.clone()
+    vals = []
+    for k in range(4):
+        losses = inst.adv_step(None, caps, m["L"], train=True)
+        inst.update_temperature(0 + (k + 1) / 50, 30)
+        vals.append(losses.tolist())
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(torch.tensor(v)).all() for v in vals)
+    assert int(inst.gen_opt.step_count) == 4 and int(inst.disc_opt.step_count) == 4
+    assert not torch.equal(before, inst.gen_arena.flat)
