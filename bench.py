@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: captions/sec of the full adversarial G+D train step (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]            # N=1 directly;
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W   # N>1: one rank per GPU over RCCL
+
+A step = one pass of the hot path over one synthetic minibatch that is already resident
+in HBM: (encoder fwd) + Decoder.sample + 3x Discriminator.forward + losses + D backward + G backward +
+2x (clip + Adam) + temperature update.  Workload = BASELINE.json configs[1] ("cfg2"): batch 64 per GPU,
+224x224 images, caption length 20, V=10000, E=H=512, 1 LSTM layer, bf16 MFMA operands with f32
+accumulation / master weights / optimizer state.  Weak scaling: every rank processes its own 64 captions.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus:
+  "roofline":     the dominant kernel replayed under HIP events on its launch stream
+  "cpu_baseline": the CPU oracle (oracle/cpu_step.py, a port pinned to the reference's golden vectors)
+                  timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG2 = dict(B=64, S=224, L=20, V=10000, E=512, H=512, NL=1)
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--batch", type=int, default=CFG2["B"], help="captions per GPU per step")
+    p.add_argument("--cgan", type=int, default=None, help="1: image-conditional (encoder in the step); default: 1 if the encoder is built")
+    p.add_argument("--encoder", default="resnet50", choices=["resnet18", "resnet50"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--step-impl", default="fused", choices=["fused", "autograd"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-steps", type=int, default=2)
+    return p.parse_args()
+
+
+def encoder_available() -> bool:
+    try:
+        from gan_image_captioning_amd import encoder_engine
+        return bool(getattr(encoder_engine, "AVAILABLE", False))
+    except Exception:
+        return False
+
+
+def build_instructor(a, cgan):
+    from gan_image_captioning_amd.args import default_args
+    from gan_image_captioning_amd.training import GANInstructor
+    args = default_args(vocab_size=CFG2["V"], gen_embed_dim=CFG2["E"], gen_hidden_dim=CFG2["H"], gen_num_layers=CFG2["NL"],
+                        conditional_gan=cgan, encoder_arch=a.encoder, compute_dtype=a.dtype, step_impl=a.step_impl,
+                        adv_train_batch_size=a.batch, image_size=CFG2["S"], device="cuda", log_file=None, model_dir=None,
+                        save_dir=None)
+    torch.manual_seed(1008)                      # src/main.py:14
+    inst = GANInstructor(args, None, None)
+    inst.gen.train()
+    inst.disc.train()
+    return inst, args
+
+
+def event_time_ms(fn, iters, stream):
+    """Average duration of fn() over `iters` back-to-back launches, HIP events on the launch stream."""
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        fn()
+    start.record(stream)
+    for _ in range(iters):
+        fn()
+    stop.record(stream)
+    stop.synchronize()
+    return start.elapsed_time(stop) / iters
+
+
+def roofline_probe(inst, args, cgan):
+    """Replay the kernel that dominates the step (rocprofv3 --stats, profiles/) with its step shapes."""
+    from gan_image_captioning_amd import engine
+    stream = torch.cuda.current_stream()
+    dev = args.device
+    if cgan:
+        from gan_image_captioning_amd import encoder_engine
+        return encoder_engine.roofline_probe(inst.gen.encoder, args, event_time_ms, MFMA_BF16_PEAK_TFLOPS)
+    # discriminator highway GEMM: [B*64, 904] x [900, 904]^T, bf16 MFMA, fused gate+dropout epilogue is separate;
+    # the plain GEMM of the same shape is the dominant launch without the encoder.
+    den = inst.disc.engine()
+    M, N, K = args.adv_train_batch_size * den.R, den.F, den.Fp
+    A = torch.randn(M, K, device=dev).to(den.act)
+    Bm = torch.randn(N, K, device=dev).to(den.act)
+    C = torch.empty(M, N, device=dev, dtype=torch.float32)
+    ms = event_time_ms(lambda: engine.gemm(A, Bm, C, M, N, K, K, K, N), 50, stream)
+    flops = 2.0 * M * N * K
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "gemm_kernel<bf16,f32,NT,64x64|128x128> highway [%d,%d,%d]" % (M, N, K), "bound": "mfma",
+            "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "ms_per_launch": round(ms, 5)}
+
+
+def cpu_baseline(a, cgan):
+    """The CPU oracle on a bounded sample of the same workload: `cpu_steps` full steps at the same batch."""
+    from oracle import cpu_step as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    g = torch.Generator().manual_seed(1008)
+    B, L, V = a.batch, CFG2["L"], CFG2["V"]
+    feat_dim = None
+    trunk_feat = None
+    if cgan:
+        from oracle import cpu_encoder as OE
+        feat_dim = OE.out_features(a.encoder)
+    gp = O.make_gen_params(V, CFG2["E"], CFG2["H"], CFG2["NL"], g, trunk_feat_dim=feat_dim)
+    dp = O.make_disc_params(V, g)
+    caps = O.make_captions(B, L, V, g)
+    us, masks = O.make_noise(B, L, V, 900, 64, g)
+    gopt, dopt = O.AdamState(1e-4), O.AdamState(1e-4)
+    if cgan:
+        tp = OE.make_trunk_params(a.encoder, g)
+        images = torch.randn(B, 3, CFG2["S"], CFG2["S"], generator=g)
+    times = []
+    for i in range(1 + a.cpu_steps):
+        t0 = time.perf_counter()
+        if cgan:
+            with torch.no_grad():
+                trunk_feat = OE.trunk_forward(tp, images, a.encoder)
+        O.adv_step(gp, dp, caps, us, masks, 1.5, "standard", 5.0, gopt, dopt, trunk_feat=trunk_feat)
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / max(1, len(times) - 1)
+    return {"value": round(B / t, 2), "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{a.cpu_steps} full steps (after 1 warm-up) of the same batch={B} workload, fp32, oracle/cpu_step.py"
+                      + (" + oracle/cpu_encoder.py trunk" if cgan else ""),
+            "ms_per_step": round(t * 1e3, 1)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    import importlib
+    importlib.import_module("gan_image_captioning_amd.build").build()
+    cgan = a.cgan if a.cgan is not None else (1 if encoder_available() else 0)
+    inst, args = build_instructor(a, cgan)
+    dev = args.device
+    from gan_image_captioning_amd.tasks import synthetic_batch
+    images, captions, _lengths, L = synthetic_batch(a.batch, CFG2["V"], CFG2["S"], CFG2["L"], seed=1008 + rank, device=dev,
+                                                    with_images=bool(cgan))
+    n_batches, adv_epochs = 50, args.adv_epochs
+
+    def step(k):
+        inst.adv_step(images, captions, L, train=True)
+        inst.update_temperature(0 + (k + 1) / n_batches, adv_epochs)      # training.py:183
+
+    for k in range(a.warmup):
+        step(k)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        step(a.warmup + k)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    if rank != 0:
+        return
+    value = world * a.batch * a.steps / elapsed
+    out = {
+        "metric": "captions/sec (G+D train step)", "value": round(value, 2), "unit": "captions/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "cfg2: adversarial G+D step, batch %d/GPU, 224x224 images, caption len 20, V=10000, E=H=512, "
+                               "1-layer LSTM G, CNN-seq D (R=64,F=900), %s" % (
+                                   a.batch, ("ResNet-50-shaped" if a.encoder == "resnet50" else "ResNet-18-shaped") + " encoder, --conditional-gan 1"
+                                   if cgan else "--conditional-gan 0 (no encoder in the step)"),
+                   "global_batch": world * a.batch, "caption_len": CFG2["L"], "image_size": CFG2["S"], "vocab": CFG2["V"],
+                   "conditional_gan": cgan, "encoder": a.encoder if cgan else None, "step_impl": a.step_impl,
+                   "parallelism": "dp%d" % world},
+    }
+    out["roofline"] = roofline_probe(inst, args, cgan)
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a, cgan)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -96,21 +96,40 @@ template <typename TA>
 __global__ __launch_bounds__(256) void disc_conv_pool_bwd_x_kernel(const float* __restrict__ dpooled, const TA* __restrict__ pooled,
                                                                      const uint8_t* __restrict__ argmax, ConvMeta cm, int L, int De, int R,
                                                                      TA* __restrict__ demb) {
-  extern __shared__ __attribute__((aligned(16))) float dx[];   // [L][s]
+  // Deterministic (no atomics): stage the gated gradient and argmax of all F filters in LDS, then each
+  // of the L*s outputs is summed by NG threads over disjoint filter subsets in a fixed order.
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
   const int br = blockIdx.x, b = br / R, r = br % R, s = cm.s;
-  for (int i = threadIdx.x; i < L * s; i += 256) dx[i] = 0.f;
-  __syncthreads();
+  const int n_out = L * s;
+  const int NG = n_out >= 256 ? 1 : 256 / n_out;
+  float* geff = lds_f;                               // [Fp]
+  float* part = lds_f + cm.Fp;                       // [NG][n_out]
+  int* tst = (int*)(part + NG * n_out);              // [Fp]
   for (int col = threadIdx.x; col < cm.F; col += 256) {
     const long o = (long)br * cm.Fp + col;
-    if (to_f32<TA>(pooled[o]) <= 0.f) continue;        // relu gate
-    const float g = dpooled[o];
-    const int k = conv_of(cm, col);
-    const int taps = cm.fsize[k] * s, ch = col - cm.foff[k], t = argmax[o];
-    for (int j = 0; j < taps; ++j) atomicAdd(&dx[t * s + j], g * cm.w[k][(long)ch * taps + j]);
+    geff[col] = to_f32<TA>(pooled[o]) > 0.f ? dpooled[o] : 0.f;     // relu gate
+    tst[col] = argmax[o];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < L * s; i += 256)
-    demb[((long)b * L + i / s) * De + r * s + i % s] = from_f32<TA>(dx[i]);
+  for (int item = threadIdx.x; item < NG * n_out; item += 256) {
+    const int o = item % n_out, grp = item / n_out;
+    const int t = o / s, e = o % s;
+    float acc = 0.f;
+    for (int col = grp; col < cm.F; col += NG) {
+      const float g = geff[col];
+      const int k = conv_of(cm, col);
+      const int dt = t - tst[col];
+      if (g != 0.f && dt >= 0 && dt < cm.fsize[k])
+        acc += g * cm.w[k][(long)(col - cm.foff[k]) * cm.fsize[k] * s + dt * s + e];
+    }
+    part[grp * n_out + o] = acc;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < n_out; o += 256) {
+    float acc = 0.f;
+    for (int g = 0; g < NG; ++g) acc += part[g * n_out + o];
+    demb[((long)b * L + o / s) * De + r * s + o % s] = from_f32<TA>(acc);
+  }
 }
 
 // ---- conv backward, weight side: block = 64 filters x 4 row lanes, rows split over gridDim.y
@@ -350,7 +369,9 @@ int disc_bwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
                        (const TA*)st->pooled, (const uint8_t*)st->argmax, (const float*)st->emb, c.cm, c.L, c.De, c.R, MR);
     GIC_CHECK_LAUNCH("disc_conv_pool_bwd_w");
   }
-  hipLaunchKernelGGL((disc_conv_pool_bwd_x_kernel<TA>), dim3((unsigned)MR), dim3(256), c.L * c.s * sizeof(float), stream,
+  const int n_out = c.L * c.s;
+  const size_t bwd_x_lds = ((size_t)2 * c.Fp + (size_t)(n_out >= 256 ? 1 : 256 / n_out) * n_out) * sizeof(float);
+  hipLaunchKernelGGL((disc_conv_pool_bwd_x_kernel<TA>), dim3((unsigned)MR), dim3(256), bwd_x_lds, stream,
                      (const float*)ws->dpooled, (const TA*)st->pooled, (const uint8_t*)st->argmax, c.cm, c.L, c.De, c.R, (TA*)ws->demb);
   GIC_CHECK_LAUNCH("disc_conv_pool_bwd_x");
   // 5. embedding backward

@@ -29,12 +29,12 @@ def disc_params(dp, dev):
     return [dp[n].to(dev).contiguous() for n in disc_param_names(O.disc_num_convs(dp))]
 
 
-def close(got, want, rtol, atol_scale=1e-5, what=""):
+def close(got, want, rtol, atol_scale=1e-5, what="", atol_abs=1e-30):
     """assert_close with an absolute floor relative to the reference tensor's largest entry."""
     got = got.detach().double().cpu()
     want = want.detach().double().cpu()
     scale = float(want.abs().max()) if want.numel() else 0.0
-    torch.testing.assert_close(got, want, rtol=rtol, atol=atol_scale * scale + 1e-30, msg=lambda s: f"{what}: {s}")
+    torch.testing.assert_close(got, want, rtol=rtol, atol=atol_scale * scale + atol_abs, msg=lambda s: f"{what}: {s}")
 
 
 def close_mostly(got, want, rtol, atol_scale, what, max_outlier_frac=5e-3, max_rel_l2=2e-3):
