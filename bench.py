@@ -34,6 +34,10 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense b
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -110,7 +114,9 @@ def roofline_probe(inst, args, cgan):
 def cpu_baseline(a, cgan):
     """The CPU oracle on a bounded sample of the same workload: `cpu_steps` full steps at the same batch."""
     from oracle import cpu_step as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # host cores actually usable here: the affinity mask, capped at the 16-core share of a 1-GPU box
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(1008)
     B, L, V = a.batch, CFG2["L"], CFG2["V"]
     feat_dim = None
@@ -128,6 +134,7 @@ def cpu_baseline(a, cgan):
         images = torch.randn(B, 3, CFG2["S"], CFG2["S"], generator=g)
     times = []
     for i in range(1 + a.cpu_steps):
+        log(f"cpu_baseline step {i}")
         t0 = time.perf_counter()
         if cgan:
             with torch.no_grad():
@@ -164,8 +171,11 @@ def main():
         inst.adv_step(images, captions, L, train=True)
         inst.update_temperature(0 + (k + 1) / n_batches, adv_epochs)      # training.py:183
 
+    log(f"instructor ready (cgan={cgan}, dtype={a.dtype}); warm-up {a.warmup} steps")
     for k in range(a.warmup):
         step(k)
+    torch.cuda.synchronize()
+    log(f"timing {a.steps} steps")
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -195,6 +205,7 @@ def main():
                    "conditional_gan": cgan, "encoder": a.encoder if cgan else None, "step_impl": a.step_impl,
                    "parallelism": "dp%d" % world},
     }
+    log(f"timed region done: {elapsed / a.steps * 1e3:.3f} ms/step; roofline probe")
     out["roofline"] = roofline_probe(inst, args, cgan)
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, cgan)

@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm must be loaded BEFORE libgicap.so: the library shares device pointers and HIP streams with
+# torch, so both have to bind to the one HIP runtime instance that torch ships (loading the system
+# libamdhip64 first gives the process two runtimes and "no ROCm-capable device" on the second).
+import torch  # noqa: F401
+
 from . import build as _build
 
 MAX_LAYERS = 4

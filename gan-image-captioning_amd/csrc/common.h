@@ -121,6 +121,22 @@ struct Philox {
     }
     out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
   }
+  // scalar-register form (no arrays: keeps the state out of scratch memory)
+  __host__ __device__ static inline void gen4(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t& o0, uint32_t& o1,
+                                               uint32_t& o2, uint32_t& o3) {
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)stream, c3 = (uint32_t)(stream >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+      const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+      const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+      const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+      c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+      k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+  }
   // U[0,1) with 24 bits, like torch's float uniform_
   __host__ __device__ static inline float u01(uint32_t bits) { return (bits >> 8) * (1.0f / 16777216.0f); }
 };

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void gumbel_softmax_argmax_kernel(
     const int oi = __shfl_xor(best_i, o, 64);
     if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
   }
+  __syncthreads();                      // block_sum's readers are done with red[]
   if ((tid & 63) == 0) { red[tid >> 6] = best; red_i[tid >> 6] = best_i; }
   __syncthreads();
   best = red[0]; best_i = red_i[0];
@@ -127,6 +128,100 @@ __global__ __launch_bounds__(256) void gumbel_softmax_argmax_kernel(
   if (tid == 0) ids[(long)b * ids_stride] = best_i;
   if (x_next)
     for (int e = tid; e < E; e += 256) x_next[(long)b * ld_x + e] = from_f32<TA>(embed[(long)best_i * E + e]);
+}
+
+// ---- register-resident variant for V % 4 == 0, V <= 4096*QPT: one 1024-thread block per row, each thread owns
+// QPT quads of 4 consecutive vocabulary entries (16-B loads of logits / u, one Philox4x32 call per quad), the row
+// is read once and never re-read; reductions = wavefront shuffles + one LDS hop.  FAST selects the hardware
+// exp/log approximations (bf16 compute mode); the f32 parity mode keeps libm-accurate logf/expf.
+template <typename TA, int QPT, bool FAST>
+__global__ __launch_bounds__(1024) void gumbel_softmax_argmax_reg_kernel(
+    const float* __restrict__ logits, const float* __restrict__ u, uint64_t seed, uint64_t rng_stream, float temperature,
+    int pretrain, TA* __restrict__ out, long out_row_stride, int64_t* __restrict__ ids, long ids_stride,
+    const float* __restrict__ embed, TA* __restrict__ x_next, long ld_x, int V, int E) {
+  __shared__ float red[16];
+  __shared__ int red_i[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* row = logits + (long)b * V;
+  TA* orow = out + (long)b * out_row_stride;
+  const float eps = 1e-10f;
+  const int nq = V >> 2;
+  float y[QPT][4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < QPT; ++e) {
+    const int q = tid + e * 1024;
+    if (q < nq) {
+      const float4 lv = *(const float4*)(row + 4 * q);
+      float yy[4] = {lv.x, lv.y, lv.z, lv.w};
+      if (!pretrain) {
+        float uu[4];
+        if (u) {
+          const float4 uv = *(const float4*)(u + (long)b * V + 4 * q);
+          uu[0] = uv.x; uu[1] = uv.y; uu[2] = uv.z; uu[3] = uv.w;
+        } else {
+          uint32_t r0, r1, r2, r3;
+          Philox::gen4(seed, rng_stream, (uint64_t)b * (uint64_t)nq + (uint64_t)q, r0, r1, r2, r3);
+          uu[0] = Philox::u01(r0); uu[1] = Philox::u01(r1); uu[2] = Philox::u01(r2); uu[3] = Philox::u01(r3);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float g = FAST ? -__logf(-__logf(uu[k] + eps) + eps) : -logf(-logf(uu[k] + eps) + eps);
+          yy[k] = (yy[k] + g) * temperature;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { y[e][k] = yy[k]; mx = fmaxf(mx, yy[k]); }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[e][k] = -INFINITY;
+    }
+  }
+  mx = block_max(mx, red);
+  float sm = 0.f;
+  float ex[QPT][4];
+#pragma unroll
+  for (int e = 0; e < QPT; ++e)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ex[e][k] = FAST ? __expf(y[e][k] - mx) : expf(y[e][k] - mx);       // exp(-inf) = 0 for the padding
+      sm += ex[e][k];
+    }
+  sm = block_sum(sm, red);
+  float best = -1.f;
+  int best_i = 0x7fffffff;
+#pragma unroll
+  for (int e = 0; e < QPT; ++e) {
+    const int q = tid + e * 1024;
+    if (q < nq) {
+      float p[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        p[k] = ex[e][k] / sm;
+        if (p[k] > best) { best = p[k]; best_i = 4 * q + k; }
+      }
+      TA o4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o4[k] = from_f32<TA>(pretrain ? y[e][k] : p[k]);
+      if constexpr (sizeof(TA) == 4) *(float4*)(orow + 4 * q) = *(const float4*)o4;
+      else *(uint2*)(orow + 4 * q) = *(const uint2*)o4;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(best_i, o, 64);
+    if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) { red[tid >> 6] = best; red_i[tid >> 6] = best_i; }
+  __syncthreads();
+  best = red[0]; best_i = red_i[0];
+  for (int w = 1; w < 16; ++w)
+    if (red[w] > best || (red[w] == best && red_i[w] < best_i)) { best = red[w]; best_i = red_i[w]; }
+  if (tid == 0) ids[(long)b * ids_stride] = best_i;
+  if (x_next)
+    for (int e = tid; e < E; e += 1024) x_next[(long)b * ld_x + e] = from_f32<TA>(embed[(long)best_i * E + e]);
 }
 
 // ---- softmax backward: dlogit = T * p * (dp - sum(dp*p))   (one block per (b,t) row)
@@ -218,9 +313,21 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
       GIC_PROPAGATE(gemm(g, stream));
     }
     TA* x_next = (TA*)st->xh[0] + (long)(t + 1) * B * c.ldx(0);
-    hipLaunchKernelGGL((gumbel_softmax_argmax_kernel<TA>), dim3(B), dim3(256), 0, stream, st->logits,
-                       noise_u ? noise_u + (long)t * B * V : nullptr, seed, (uint64_t)t, temperature, pretrain,
-                       (TA*)out + (long)t * V, (long)L * V, ids + t, (long)L, P->embed, x_next, c.ldx(0), V, E);
+    const float* u_t = noise_u ? noise_u + (long)t * B * V : nullptr;
+    constexpr bool kFast = sizeof(TA) == 2;
+    if (V % 4 == 0 && V <= 4096) {
+      hipLaunchKernelGGL((gumbel_softmax_argmax_reg_kernel<TA, 1, kFast>), dim3(B), dim3(1024), 0, stream, (const float*)st->logits,
+                         u_t, seed, (uint64_t)t, temperature, pretrain, (TA*)out + (long)t * V, (long)L * V, ids + t, (long)L,
+                         P->embed, x_next, c.ldx(0), V, E);
+    } else if (V % 4 == 0 && V <= 16384) {
+      hipLaunchKernelGGL((gumbel_softmax_argmax_reg_kernel<TA, 4, kFast>), dim3(B), dim3(1024), 0, stream, (const float*)st->logits,
+                         u_t, seed, (uint64_t)t, temperature, pretrain, (TA*)out + (long)t * V, (long)L * V, ids + t, (long)L,
+                         P->embed, x_next, c.ldx(0), V, E);
+    } else {
+      hipLaunchKernelGGL((gumbel_softmax_argmax_kernel<TA>), dim3(B), dim3(256), 0, stream, st->logits, u_t, seed, (uint64_t)t,
+                         temperature, pretrain, (TA*)out + (long)t * V, (long)L * V, ids + t, (long)L, P->embed, x_next,
+                         c.ldx(0), V, E);
+    }
     GIC_CHECK_LAUNCH("gumbel_softmax_argmax");
   }
   return GIC_OK;

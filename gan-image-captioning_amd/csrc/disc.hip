@@ -59,7 +59,7 @@ __global__ void disc_emb_scatter_kernel(const float* __restrict__ demb_f32, cons
 }
 
 // ---- fused conv + bias + ReLU + max-over-time.  grid = B*R blocks, 256 threads stride over the F filters.
-template <typename TA>
+template <typename TA, int MAXT>
 __global__ __launch_bounds__(256) void disc_conv_pool_fwd_kernel(const float* __restrict__ emb, ConvMeta cm, int L, int De, int R,
                                                                    TA* __restrict__ pooled, uint8_t* __restrict__ argmax) {
   extern __shared__ __attribute__((aligned(16))) float xs[];   // [L][s]
@@ -72,15 +72,15 @@ __global__ __launch_bounds__(256) void disc_conv_pool_fwd_kernel(const float* __
     if (col < cm.F) {
       const int k = conv_of(cm, col);
       const int f = cm.fsize[k], ch = col - cm.foff[k], taps = f * s;
-      float w[kMaxTaps];
+      float w[MAXT];
 #pragma unroll
-      for (int j = 0; j < kMaxTaps; ++j) w[j] = j < taps ? cm.w[k][(long)ch * taps + j] : 0.f;
+      for (int j = 0; j < MAXT; ++j) w[j] = j < taps ? cm.w[k][(long)ch * taps + j] : 0.f;
       const float bias = cm.b[k][ch];
       best = -1.f;
       for (int t = 0; t + f <= L; ++t) {
         float v = bias;
 #pragma unroll
-        for (int j = 0; j < kMaxTaps; ++j)
+        for (int j = 0; j < MAXT; ++j)
           if (j < taps) v += w[j] * xs[t * s + j];      // window (t..t+f-1) x s is contiguous in xs
         v = fmaxf(v, 0.f);                              // relu then max (discriminator.py:42,45)
         if (v > best) { best = v; bt = t; }
@@ -104,7 +104,18 @@ __global__ __launch_bounds__(256) void disc_conv_pool_bwd_x_kernel(const float* 
   const int NG = n_out >= 256 ? 1 : 256 / n_out;
   float* geff = lds_f;                               // [Fp]
   float* part = lds_f + cm.Fp;                       // [NG][n_out]
-  int* tst = (int*)(part + NG * n_out);              // [Fp]
+  int* tst = (int*)(part + NG * n_out);              // [Fp]  argmax time
+  int* meta = tst + cm.Fp;                           // [Fp]  (taps << 20) | offset of the filter's weights in wl
+  float* wl = (float*)(meta + cm.Fp);                // all conv weights, filter-major
+  {
+    int woff = 0;
+    for (int k = 0; k < cm.nconv; ++k) {
+      const int taps = cm.fsize[k] * s, nw = cm.nfilt[k] * taps;
+      for (int i = threadIdx.x; i < nw; i += 256) wl[woff + i] = cm.w[k][i];
+      for (int ch = threadIdx.x; ch < cm.nfilt[k]; ch += 256) meta[cm.foff[k] + ch] = (taps << 20) | (woff + ch * taps);
+      woff += nw;
+    }
+  }
   for (int col = threadIdx.x; col < cm.F; col += 256) {
     const long o = (long)br * cm.Fp + col;
     geff[col] = to_f32<TA>(pooled[o]) > 0.f ? dpooled[o] : 0.f;     // relu gate
@@ -117,10 +128,9 @@ __global__ __launch_bounds__(256) void disc_conv_pool_bwd_x_kernel(const float* 
     float acc = 0.f;
     for (int col = grp; col < cm.F; col += NG) {
       const float g = geff[col];
-      const int k = conv_of(cm, col);
-      const int dt = t - tst[col];
-      if (g != 0.f && dt >= 0 && dt < cm.fsize[k])
-        acc += g * cm.w[k][(long)(col - cm.foff[k]) * cm.fsize[k] * s + dt * s + e];
+      const int mt = meta[col];
+      const int dtap = (t - tst[col]) * s + e;       // tap index of this output inside the filter's window
+      if (g != 0.f && dtap >= e && dtap < (mt >> 20)) acc += g * wl[(mt & 0xFFFFF) + dtap];
     }
     part[grp * n_out + o] = acc;
   }
@@ -281,8 +291,14 @@ int disc_fwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
     GIC_PROPAGATE(gemm(g, stream));
   }
   // 2. conv + relu + max over time
-  hipLaunchKernelGGL((disc_conv_pool_fwd_kernel<TA>), dim3((unsigned)c.rowsBR), dim3(256), c.L * c.s * sizeof(float), stream,
-                     (const float*)st->emb, c.cm, c.L, c.De, c.R, (TA*)st->pooled, st->argmax);
+  int max_taps = 0;
+  for (int k = 0; k < c.cm.nconv; ++k) max_taps = c.cm.fsize[k] * c.s > max_taps ? c.cm.fsize[k] * c.s : max_taps;
+  if (max_taps <= 8)
+    hipLaunchKernelGGL((disc_conv_pool_fwd_kernel<TA, 8>), dim3((unsigned)c.rowsBR), dim3(256), c.L * c.s * sizeof(float), stream,
+                       (const float*)st->emb, c.cm, c.L, c.De, c.R, (TA*)st->pooled, st->argmax);
+  else
+    hipLaunchKernelGGL((disc_conv_pool_fwd_kernel<TA, kMaxTaps>), dim3((unsigned)c.rowsBR), dim3(256), c.L * c.s * sizeof(float), stream,
+                       (const float*)st->emb, c.cm, c.L, c.De, c.R, (TA*)st->pooled, st->argmax);
   GIC_CHECK_LAUNCH("disc_conv_pool_fwd");
   // 3. highway + dropout (fused epilogue)
   {
@@ -370,7 +386,10 @@ int disc_bwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
     GIC_CHECK_LAUNCH("disc_conv_pool_bwd_w");
   }
   const int n_out = c.L * c.s;
-  const size_t bwd_x_lds = ((size_t)2 * c.Fp + (size_t)(n_out >= 256 ? 1 : 256 / n_out) * n_out) * sizeof(float);
+  size_t conv_w_total = 0;
+  for (int k = 0; k < c.cm.nconv; ++k) conv_w_total += (size_t)c.cm.nfilt[k] * c.cm.fsize[k] * c.s;
+  const size_t bwd_x_lds = ((size_t)3 * c.Fp + (size_t)(n_out >= 256 ? 1 : 256 / n_out) * n_out + conv_w_total) * sizeof(float);
+  GIC_CHECK_ARG(bwd_x_lds <= 160 * 1024, "disc_bwd: conv weights (%zu floats) do not fit the LDS staging", conv_w_total);
   hipLaunchKernelGGL((disc_conv_pool_bwd_x_kernel<TA>), dim3((unsigned)MR), dim3(256), bwd_x_lds, stream,
                      (const float*)ws->dpooled, (const TA*)st->pooled, (const uint8_t*)st->argmax, c.cm, c.L, c.De, c.R, (TA*)ws->demb);
   GIC_CHECK_LAUNCH("disc_conv_pool_bwd_x");

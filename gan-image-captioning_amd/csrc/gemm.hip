@@ -1,6 +1,6 @@
 // MFMA GEMM family for gfx950 (MI355X).  One templated kernel covers every dense
 // contraction on the hot path (LSTM gates, vocab projection, discriminator
-// embedding / highway / head, all dgrad and wgrad products):
+// embedding / highway / head, all dgrad and wgrad products, the encoder head):
 //
 //  * 16x16 MFMA tiles: v_mfma_f32_16x16x32_bf16 (bf16 in, f32 acc) or
 //    v_mfma_f32_16x16x4_f32 (exact f32 fma chain; parity mode).
@@ -10,9 +10,11 @@
 //    m/n-contiguous (LDS image [k][row]; bf16 fragments come out of
 //    ds_read_b64_tr_b16, the gfx950 transposing LDS read) so dgrad / wgrad need
 //    no transposed copies in HBM.
-//  * global -> VGPR -> LDS staging with the next tile's loads in flight under the
-//    current tile's MFMAs; 16-byte loads/stores when shapes allow, scalar fallback
-//    otherwise (odd test shapes).
+//  * global -> VGPR -> LDS staging, two LDS buffers: tile k+1's global loads are issued
+//    before tile k's MFMAs and written to the other buffer after them; one barrier per
+//    K tile.  16-byte loads/stores when shapes allow, scalar fallback otherwise.
+//  * split-K over gridDim.y (f32 atomic accumulate) for the skinny recurrent products
+//    (M = batch) that would otherwise occupy a handful of CUs.
 //  * XCD-aware block -> tile map: each of the 8 XCDs owns a contiguous run of
 //    tiles that share B (weight) panels in its private L2.
 #include "gemm.h"
@@ -22,9 +24,13 @@ namespace gic {
 namespace {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4* gptr_u4;
+
+template <typename T> struct GlobalPtr { typedef const __attribute__((address_space(1))) T* type; };
 
 template <typename TI, typename TO, bool AKC, bool BKC, int BM, int BN, bool VEC, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d) {
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k_tiles_per_split) {
   constexpr int SZ = sizeof(TI);
   constexpr int BK = 128 / SZ;          // K elements per tile
   constexpr int VE = 16 / SZ;           // elements per 16-byte chunk
@@ -32,13 +38,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d) {
   constexpr int SB = BKC ? 144 : BN * SZ + 16;
   constexpr int A_BYTES = AKC ? BM * SA : BK * SA;
   constexpr int B_BYTES = BKC ? BN * SB : BK * SB;
+  constexpr int BUF_BYTES = A_BYTES + B_BYTES;
   constexpr int TM = BM / 32, TN = BN / 32;      // 16x16 tiles per wave
   constexpr int CA = BM / 32, CB = BN / 32;      // 16-B chunks per thread per tile
   constexpr bool IS_BF16 = (SZ == 2);
+  typedef typename GlobalPtr<TI>::type gptr_t;
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
-  unsigned char* sA = smem;
-  unsigned char* sB = smem + A_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 1, wc = w & 1;
@@ -55,8 +61,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d) {
   const int bm0 = (bid % tiles_m) * BM;
   const int bn0 = (bid / tiles_m) * BN;
 
-  const TI* __restrict__ A = (const TI*)d.A;
-  const TI* __restrict__ B = (const TI*)d.B;
+  gptr_t A = (gptr_t)d.A;
+  gptr_t B = (gptr_t)d.B;
   const int M = d.M, N = d.N, K = d.K;
   const long lda = d.lda, ldb = d.ldb;
 
@@ -66,94 +72,103 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[CA], rb[CB];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  u32x4 ra[CA], rb[CB];
 
+  // global -> registers (VEC path).  Typed address_space(1) loads: a `cond ? *p : zero` on a generic pointer
+  // makes the compiler select between the global address and a private zero and spill the staging registers.
   auto gload = [&](int kt) {
     if constexpr (VEC) {
       const int k0 = kt * BK;
 #pragma unroll
       for (int i = 0; i < CA; ++i) {
         const int c = tid + i * 256;
+        ra[i] = (u32x4){0u, 0u, 0u, 0u};
         if constexpr (AKC) {
-          const int row = c >> 3, kc = c & 7;
-          const int m = bm0 + row, k = k0 + kc * VE;
-          ra[i] = (m < M && k < K) ? *(const uint4*)(A + (long)m * lda + k) : zero4;
+          const int m = bm0 + (c >> 3), k = k0 + (c & 7) * VE;
+          if (m < M && k < K) ra[i] = *(gptr_u4)(A + (long)m * lda + k);
         } else {
           constexpr int CPR = BM / VE;
-          const int krow = c / CPR, mc = c % CPR;
-          const int k = k0 + krow, m = bm0 + mc * VE;
-          ra[i] = (k < K && m < M) ? *(const uint4*)(A + (long)k * lda + m) : zero4;
+          const int k = k0 + c / CPR, m = bm0 + (c % CPR) * VE;
+          if (k < K && m < M) ra[i] = *(gptr_u4)(A + (long)k * lda + m);
         }
       }
 #pragma unroll
       for (int i = 0; i < CB; ++i) {
         const int c = tid + i * 256;
+        rb[i] = (u32x4){0u, 0u, 0u, 0u};
         if constexpr (BKC) {
-          const int row = c >> 3, kc = c & 7;
-          const int n = bn0 + row, k = k0 + kc * VE;
-          rb[i] = (n < N && k < K) ? *(const uint4*)(B + (long)n * ldb + k) : zero4;
+          const int n = bn0 + (c >> 3), k = k0 + (c & 7) * VE;
+          if (n < N && k < K) rb[i] = *(gptr_u4)(B + (long)n * ldb + k);
         } else {
           constexpr int CPR = BN / VE;
-          const int krow = c / CPR, nc = c % CPR;
-          const int k = k0 + krow, n = bn0 + nc * VE;
-          rb[i] = (k < K && n < N) ? *(const uint4*)(B + (long)k * ldb + n) : zero4;
+          const int k = k0 + c / CPR, n = bn0 + (c % CPR) * VE;
+          if (k < K && n < N) rb[i] = *(gptr_u4)(B + (long)k * ldb + n);
         }
       }
     }
   };
 
-  auto sstore = [&](int kt) {
+  // registers (VEC) or global (scalar fallback) -> LDS buffer `buf`
+  auto sstore = [&](int kt, int buf) {
+    unsigned char* sA = smem + buf * BUF_BYTES;
+    unsigned char* sB = sA + A_BYTES;
     if constexpr (VEC) {
 #pragma unroll
       for (int i = 0; i < CA; ++i) {
         const int c = tid + i * 256;
         if constexpr (AKC) {
-          *(uint4*)(sA + (c >> 3) * SA + (c & 7) * 16) = ra[i];
+          *(u32x4*)(sA + (c >> 3) * SA + (c & 7) * 16) = ra[i];
         } else {
           constexpr int CPR = BM / VE;
-          *(uint4*)(sA + (c / CPR) * SA + (c % CPR) * 16) = ra[i];
+          *(u32x4*)(sA + (c / CPR) * SA + (c % CPR) * 16) = ra[i];
         }
       }
 #pragma unroll
       for (int i = 0; i < CB; ++i) {
         const int c = tid + i * 256;
         if constexpr (BKC) {
-          *(uint4*)(sB + (c >> 3) * SB + (c & 7) * 16) = rb[i];
+          *(u32x4*)(sB + (c >> 3) * SB + (c & 7) * 16) = rb[i];
         } else {
           constexpr int CPR = BN / VE;
-          *(uint4*)(sB + (c / CPR) * SB + (c % CPR) * 16) = rb[i];
+          *(u32x4*)(sB + (c / CPR) * SB + (c % CPR) * 16) = rb[i];
         }
       }
     } else {
-      // scalar fallback: element-wise guarded copy (odd shapes / unaligned leading dims)
       const int k0 = kt * BK;
       for (int e = tid; e < BM * BK; e += 256) {
+        TI v = (TI)0.f;
         if constexpr (AKC) {
           const int row = e / BK, kk = e % BK;
           const int m = bm0 + row, k = k0 + kk;
-          *(TI*)(sA + row * SA + kk * SZ) = (m < M && k < K) ? A[(long)m * lda + k] : (TI)0.f;
+          if (m < M && k < K) v = A[(long)m * lda + k];
+          *(TI*)(sA + row * SA + kk * SZ) = v;
         } else {
           const int kk = e / BM, row = e % BM;
           const int m = bm0 + row, k = k0 + kk;
-          *(TI*)(sA + kk * SA + row * SZ) = (m < M && k < K) ? A[(long)k * lda + m] : (TI)0.f;
+          if (m < M && k < K) v = A[(long)k * lda + m];
+          *(TI*)(sA + kk * SA + row * SZ) = v;
         }
       }
       for (int e = tid; e < BN * BK; e += 256) {
+        TI v = (TI)0.f;
         if constexpr (BKC) {
           const int row = e / BK, kk = e % BK;
           const int n = bn0 + row, k = k0 + kk;
-          *(TI*)(sB + row * SB + kk * SZ) = (n < N && k < K) ? B[(long)n * ldb + k] : (TI)0.f;
+          if (n < N && k < K) v = B[(long)n * ldb + k];
+          *(TI*)(sB + row * SB + kk * SZ) = v;
         } else {
           const int kk = e / BN, row = e % BN;
           const int n = bn0 + row, k = k0 + kk;
-          *(TI*)(sB + kk * SB + row * SZ) = (n < N && k < K) ? B[(long)k * ldb + n] : (TI)0.f;
+          if (n < N && k < K) v = B[(long)k * ldb + n];
+          *(TI*)(sB + kk * SB + row * SZ) = v;
         }
       }
     }
   };
 
-  auto compute = [&]() {
+  auto compute = [&](int buf) {
+    const unsigned char* sA = smem + buf * BUF_BYTES;
+    const unsigned char* sB = sA + A_BYTES;
     if constexpr (IS_BF16) {
 #pragma unroll
       for (int ks = 0; ks < BK / 32; ++ks) {
@@ -229,32 +244,57 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d) {
     }
   };
 
+  // ---- K loop over this block's split: [kt0, kt1)
   const int nk = (K + BK - 1) / BK;
-  gload(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    sstore(kt);
+  const int kt0 = blockIdx.y * k_tiles_per_split;
+  const int kt1 = min(nk, kt0 + k_tiles_per_split);
+  if (kt0 < kt1) {
+    int cur = 0;
+    gload(kt0);
+    sstore(kt0, 0);
     __syncthreads();
-    if (kt + 1 < nk) gload(kt + 1);     // next tile's HBM/L2 loads fly under this tile's MFMAs
-    compute();
-    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const bool more = kt + 1 < kt1;
+      if (more) gload(kt + 1);          // next tile's HBM/L2 loads fly under this tile's MFMAs
+      compute(cur);
+      if (more) sstore(kt + 1, cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
   // ---- epilogue.  C/D map: col = lane&15, row = (lane>>4)*4 + reg
   TO* __restrict__ C = (TO*)d.C;
+  const bool split = gridDim.y > 1;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = bn0 + wc * (BN / 2) + j * 16 + lr;
       if (n >= N) continue;
-      const float bias = d.bias ? d.bias[n] : 0.f;
+      const float bias = (d.bias && blockIdx.y == 0) ? d.bias[n] : 0.f;
+      const int mb = bm0 + wr * (BM / 2) + i * 16 + lg * 4;
+      float keep4[4] = {1.f, 1.f, 1.f, 1.f};
+      if constexpr (EPI == EPI_HIGHWAY) {
+        if (!d.mask && d.use_philox) {       // one Philox4x32 call serves the lane's 4 consecutive rows
+          uint32_t r0, r1, r2, r3;
+          Philox::gen4(d.seed, d.stream, (uint64_t)(mb >> 2) * (uint64_t)N + (uint64_t)n, r0, r1, r2, r3);
+          keep4[0] = Philox::u01(r0) >= d.drop_p ? 1.f : 0.f;
+          keep4[1] = Philox::u01(r1) >= d.drop_p ? 1.f : 0.f;
+          keep4[2] = Philox::u01(r2) >= d.drop_p ? 1.f : 0.f;
+          keep4[3] = Philox::u01(r3) >= d.drop_p ? 1.f : 0.f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = bm0 + wr * (BM / 2) + i * 16 + lg * 4 + r;
+        const int m = mb + r;
         if (m >= M) continue;
         float v = d.alpha * acc[i][j][r] + bias;
         if constexpr (EPI == EPI_PLAIN) {
           const long o = (long)m * d.ldc + n;
+          if constexpr (sizeof(TO) == 4) {
+            if (split) { atomicAdd((float*)&C[o], v); continue; }
+          }
           if (d.accumulate) v += to_f32<TO>(C[o]);
           C[o] = from_f32<TO>(v);
         } else {   // EPI_HIGHWAY
@@ -262,15 +302,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d) {
           const float sg = 1.f / (1.f + expf(-v));
           const float y = sg * fmaxf(v, 0.f) + (1.f - sg) * x;
           d.Hpre[(long)m * d.ldh + n] = v;
-          float keep = 1.f;
-          if (d.mask) {
-            keep = (float)d.mask[(long)m * d.ldmask + n];
-          } else if (d.use_philox) {
-            uint32_t rnd[4];
-            const uint64_t idx = (uint64_t)m * (uint64_t)N + (uint64_t)n;
-            Philox::gen(d.seed, d.stream, idx >> 2, rnd);
-            keep = Philox::u01(rnd[idx & 3]) >= d.drop_p ? 1.f : 0.f;
-          }
+          float keep = keep4[r];
+          if (d.mask) keep = (float)d.mask[(long)m * d.ldmask + n];
           if (d.mask_out) d.mask_out[(long)m * d.ldmask_out + n] = (uint8_t)keep;
           C[(long)m * d.ldc + n] = from_f32<TO>(y * keep * d.keep_scale);
         }
@@ -279,10 +312,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d) {
   }
 }
 
+__global__ void zero2d_kernel(float* __restrict__ C, long ldc, int M, int N) {
+  const long total = (long)M * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    C[(i / N) * ldc + (i % N)] = 0.f;
+}
+
 template <typename TI, typename TO, bool AKC, bool BKC, int BM, int BN, bool VEC, int EPI>
 int launch(const GemmDesc& d, hipStream_t stream) {
+  constexpr int BK = 128 / (int)sizeof(TI);
   const int tiles = cdiv(d.M, BM) * cdiv(d.N, BN);
-  hipLaunchKernelGGL((gemm_kernel<TI, TO, AKC, BKC, BM, BN, VEC, EPI>), dim3(tiles), dim3(256), 0, stream, d);
+  const int nk = cdiv(d.K, BK);
+  // split-K only where the tile grid leaves most of the 256 CUs idle and K is deep enough to share
+  int splits = 1;
+  // (bf16 compute mode only: the f32 parity mode stays bit-reproducible run to run, atomics reorder the f32 sum)
+  if (EPI == EPI_PLAIN && sizeof(TI) == 2 && sizeof(TO) == 4 && tiles < 96 && nk >= 8) {
+    splits = 256 / tiles;
+    if (splits > nk / 2) splits = nk / 2;
+    if (splits > 16) splits = 16;
+    if (splits < 1) splits = 1;
+  }
+  int per = cdiv(nk, splits);
+  splits = cdiv(nk, per);
+  if (splits > 1 && !d.accumulate) {
+    const long total = (long)d.M * d.N;
+    const int g = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+    hipLaunchKernelGGL(zero2d_kernel, dim3(g), dim3(256), 0, stream, (float*)d.C, d.ldc, d.M, d.N);
+  }
+  hipLaunchKernelGGL((gemm_kernel<TI, TO, AKC, BKC, BM, BN, VEC, EPI>), dim3(tiles, splits), dim3(256), 0, stream, d, per);
   GIC_CHECK_LAUNCH("gemm");
   return GIC_OK;
 }
