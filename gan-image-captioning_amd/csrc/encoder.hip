@@ -1,0 +1,357 @@
+// Image encoder (reference src/generator.py:8-25): ResNet trunk forward (no_grad, BatchNorm on batch
+// statistics) + the trainable Linear/BatchNorm1d head.
+//
+// Activations are NHWC in the compute dtype, so a convolution is the implicit GEMM
+//   out[(n,ho,wo), cout] = sum_{(r,s,c)} in[n, ho*st-pad+r, wo*st-pad+s, c] * w[cout, r, s, c]
+// run by the MFMA GEMM kernel (gemm.hip, CONV loader) with the BatchNorm statistics (per-channel sum and
+// sum of squares of the f32 accumulators) reduced in its epilogue.  Everything else here is memory-bound
+// element-wise work with 16-byte accesses along the channel axis:
+//   pack_image        NCHW f32 -> zero-bordered NHWC4 (3 channels + 1 zero) so the 7x7 stem is a plain
+//                     [7 x 8 x 4] window with no bounds checks
+//   bn_act            y -> relu(bn(y) + residual | bn(residual))
+//   bn_relu_maxpool   stem: bn + relu + 3x3/2 max-pool in one pass
+//   avgpool           global average pool
+//   bn1d_fwd / bwd    the head's BatchNorm1d(momentum=0.01) on [B, E]
+#include "../../include/gicap.h"
+#include "kernels.h"
+
+namespace gic {
+namespace {
+
+constexpr float kBnEps = 1e-5f;
+
+// ---- NCHW f32 [N,3,S,S] -> [N, S+2*pad, Wp, 4] act, zero border and zero 4th channel
+template <typename TA>
+__global__ void pack_image_kernel(const float* __restrict__ img, TA* __restrict__ out, int N, int S, int pad, int Hp, int Wp) {
+  const long total = (long)N * Hp * Wp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int wp = (int)(i % Wp);
+    const long t = i / Wp;
+    const int hp = (int)(t % Hp), n = (int)(t / Hp);
+    const int h = hp - pad, w = wp - pad;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (h >= 0 && h < S && w >= 0 && w < S) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = img[(((long)n * 3 + c) * S + h) * S + w];
+    }
+    TA* o = out + i * 4;
+    o[0] = from_f32<TA>(v[0]); o[1] = from_f32<TA>(v[1]); o[2] = from_f32<TA>(v[2]); o[3] = from_f32<TA>(0.f);
+  }
+}
+
+// ---- conv weight [Cout, Cin, KH, KW] f32 -> [Cout, KH, KWp, Cinp] act (zero padded taps / channels)
+template <typename TA>
+__global__ void repack_conv_weight_kernel(const float* __restrict__ w, TA* __restrict__ out, int Cout, int Cin, int KH, int KW,
+                                          int Cinp, int KWp) {
+  const long total = (long)Cout * KH * KWp * Cinp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cinp);
+    long t = i / Cinp;
+    const int s = (int)(t % KWp); t /= KWp;
+    const int r = (int)(t % KH);
+    const int co = (int)(t / KH);
+    float v = 0.f;
+    if (c < Cin && s < KW) v = w[(((long)co * Cin + c) * KH + r) * KW + s];
+    out[i] = from_f32<TA>(v);
+  }
+}
+
+struct BnSrc {            // y-side or residual-side BatchNorm inputs; stats == nullptr -> identity (no BN)
+  const float* stats;     // [2C]: sum, sum of squares
+  const float* gamma;
+  const float* beta;
+  const float* run_mean;  // eval mode (stats == nullptr but run_mean != nullptr)
+  const float* run_var;
+};
+
+__device__ __forceinline__ void bn_coeffs(const BnSrc& b, int c, int C, float inv_count, float& scale, float& shift) {
+  float mean, var;
+  if (b.stats) {
+    mean = b.stats[c] * inv_count;
+    var = fmaxf(b.stats[C + c] * inv_count - mean * mean, 0.f);
+  } else if (b.run_mean) {
+    mean = b.run_mean[c]; var = b.run_var[c];
+  } else { scale = 1.f; shift = 0.f; return; }
+  scale = b.gamma[c] * rsqrtf(var + kBnEps);
+  shift = b.beta[c] - mean * scale;
+}
+
+// ---- out = [relu]( bn(y) + (res ? bn_res(res) : 0) ), rows x C, 4 channels per thread.
+// The launch makes gridDim.x*256 a multiple of C/4, so a thread keeps ONE channel quad for all its rows and
+// derives its BatchNorm scale/shift (from the raw sums) once.
+template <typename TA>
+__global__ void bn_act_kernel(const TA* __restrict__ y, BnSrc by, const TA* __restrict__ res, BnSrc br, float inv_count, int relu,
+                              TA* __restrict__ out, long rows, int C) {
+  const int cq = C >> 2;
+  const long total = rows * cq;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = (int)(i0 % cq) * 4;
+  float sc[4], sh[4], rs[4] = {1.f, 1.f, 1.f, 1.f}, rh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    bn_coeffs(by, c0 + k, C, inv_count, sc[k], sh[k]);
+    if (res) bn_coeffs(br, c0 + k, C, inv_count, rs[k], rh[k]);
+  }
+  for (long i = i0; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long o = (i / cq) * C + c0;
+    float v[4];
+    TA yv[4], rv[4];
+    if constexpr (sizeof(TA) == 4) *(float4*)yv = *(const float4*)(y + o); else *(uint2*)yv = *(const uint2*)(y + o);
+    if (res) { if constexpr (sizeof(TA) == 4) *(float4*)rv = *(const float4*)(res + o); else *(uint2*)rv = *(const uint2*)(res + o); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = to_f32<TA>(yv[k]) * sc[k] + sh[k];
+      if (res) v[k] += to_f32<TA>(rv[k]) * rs[k] + rh[k];
+      if (relu) v[k] = fmaxf(v[k], 0.f);
+    }
+    TA o4[4] = {from_f32<TA>(v[0]), from_f32<TA>(v[1]), from_f32<TA>(v[2]), from_f32<TA>(v[3])};
+    if constexpr (sizeof(TA) == 4) *(float4*)(out + o) = *(const float4*)o4;
+    else *(uint2*)(out + o) = *(const uint2*)o4;
+  }
+}
+
+// ---- stem: relu(bn(y)) then 3x3 stride-2 pad-1 max-pool.  y [N,H,W,C] -> out [N,Ho,Wo,C]
+template <typename TA>
+__global__ void bn_relu_maxpool_kernel(const TA* __restrict__ y, BnSrc by, float inv_count, TA* __restrict__ out, int N, int H, int W,
+                                       int C, int Ho, int Wo) {
+  const int cq = C >> 2;
+  const long total = (long)N * Ho * Wo * cq;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cq) * 4;
+    long t = i / cq;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float sc[4], sh[4], best[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { bn_coeffs(by, c0 + k, C, inv_count, sc[k], sh[k]); best[k] = -INFINITY; }
+    for (int r = 0; r < 3; ++r) {
+      const int h = ho * 2 - 1 + r;
+      if (h < 0 || h >= H) continue;
+      for (int s = 0; s < 3; ++s) {
+        const int w = wo * 2 - 1 + s;
+        if (w < 0 || w >= W) continue;
+        const TA* p = y + (((long)n * H + h) * W + w) * C + c0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) best[k] = fmaxf(best[k], fmaxf(to_f32<TA>(p[k]) * sc[k] + sh[k], 0.f));
+      }
+    }
+    TA* o = out + (((long)n * Ho + ho) * Wo + wo) * C + c0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = from_f32<TA>(best[k]);
+  }
+}
+
+// ---- global average pool: x [N, HW, C] -> out [N, C] (act) ; one thread per (n, c)
+template <typename TA>
+__global__ void avgpool_kernel(const TA* __restrict__ x, TA* __restrict__ out, int N, int HW, int C) {
+  const long total = (long)N * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long n = i / C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += to_f32<TA>(x[(n * HW + p) * C + c]);
+    out[i] = from_f32<TA>(s / (float)HW);
+  }
+}
+
+// ---- running statistics of every BatchNorm2d of the trunk in one launch (table built once by the host)
+__global__ void bn_running_update_kernel(const gic_bn_running_desc* __restrict__ table, int nlayers) {
+  const int l = blockIdx.x;
+  if (l >= nlayers) return;
+  const gic_bn_running_desc d = table[l];
+  const float inv = 1.f / d.count;
+  const float unbias = d.count > 1.f ? d.count / (d.count - 1.f) : 1.f;
+  for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+    const float mean = d.stats[c] * inv;
+    const float var = fmaxf(d.stats[d.C + c] * inv - mean * mean, 0.f);
+    d.running_mean[c] = (1.f - d.momentum) * d.running_mean[c] + d.momentum * mean;
+    d.running_var[c] = (1.f - d.momentum) * d.running_var[c] + d.momentum * var * unbias;
+  }
+}
+
+// ---- BatchNorm1d over the batch axis of x [B,E]; one wave per feature column group
+__global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                        float* __restrict__ run_var, int training, float momentum, float eps,
+                                                        float* __restrict__ y, float* __restrict__ xhat, float* __restrict__ invstd,
+                                                        int B, int E) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float mean, var;
+  if (training) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += x[(long)b * E + e];
+    mean = s / (float)B;
+    float q = 0.f;
+    for (int b = 0; b < B; ++b) { const float d = x[(long)b * E + e] - mean; q += d * d; }
+    var = q / (float)B;
+    run_mean[e] = (1.f - momentum) * run_mean[e] + momentum * mean;
+    run_var[e] = (1.f - momentum) * run_var[e] + momentum * var * (B > 1 ? (float)B / (float)(B - 1) : 1.f);
+  } else {
+    mean = run_mean[e]; var = run_var[e];
+  }
+  const float is = rsqrtf(var + eps);
+  invstd[e] = is;
+  const float g = gamma[e], bt = beta[e];
+  for (int b = 0; b < B; ++b) {
+    const float xh = (x[(long)b * E + e] - mean) * is;
+    xhat[(long)b * E + e] = xh;
+    y[(long)b * E + e] = xh * g + bt;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                        int training, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, int B, int E) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float sg = 0.f, sb = 0.f;
+  for (int b = 0; b < B; ++b) { const float d = dy[(long)b * E + e]; sg += d * xhat[(long)b * E + e]; sb += d; }
+  dgamma[e] = sg;
+  dbeta[e] = sb;
+  const float k = gamma[e] * invstd[e];
+  const float invB = 1.f / (float)B;
+  for (int b = 0; b < B; ++b) {
+    const float d = dy[(long)b * E + e];
+    dx[(long)b * E + e] = training ? k * (d - invB * (sb + xhat[(long)b * E + e] * sg)) : k * d;
+  }
+}
+
+inline int grid1d(long total, int cap = 4096) {
+  long g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+// grid whose total thread count is a multiple of `period` work items (period = C/4, a power of two here)
+inline int grid_periodic(long total, int period, int cap = 4096) {
+  int g = grid1d(total, cap);
+  const int mult = period > 256 ? period / 256 : 1;
+  g = (g + mult - 1) / mult * mult;
+  return g;
+}
+
+BnSrc make_src(const float* stats, const float* gamma, const float* beta, const float* rm, const float* rv) {
+  BnSrc s;
+  s.stats = stats; s.gamma = gamma; s.beta = beta; s.run_mean = rm; s.run_var = rv;
+  return s;
+}
+
+}  // namespace
+}  // namespace gic
+
+using namespace gic;
+
+extern "C" {
+
+int gic_pack_image(const float* nchw, void* out, int dtype, int N, int S, int pad, int Wp, void* stream) {
+  GIC_CHECK_ARG(nchw && out && N > 0 && S > 0 && pad >= 0 && Wp >= S + 2 * pad, "pack_image: bad argument");
+  const int Hp = S + 2 * pad;
+  const long total = (long)N * Hp * Wp;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL((pack_image_kernel<float>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, nchw, (float*)out, N, S, pad, Hp, Wp);
+  else
+    hipLaunchKernelGGL((pack_image_kernel<bf16_t>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, nchw, (bf16_t*)out, N, S, pad, Hp, Wp);
+  GIC_CHECK_LAUNCH("pack_image");
+  return GIC_OK;
+}
+
+int gic_repack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cin_pad, int KW_pad, void* stream) {
+  GIC_CHECK_ARG(w && out && Cin_pad >= Cin && KW_pad >= KW, "repack_conv_weight: bad argument");
+  const long total = (long)Cout * KH * KW_pad * Cin_pad;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL((repack_conv_weight_kernel<float>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, w, (float*)out, Cout, Cin, KH, KW, Cin_pad, KW_pad);
+  else
+    hipLaunchKernelGGL((repack_conv_weight_kernel<bf16_t>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)out, Cout, Cin, KH, KW, Cin_pad, KW_pad);
+  GIC_CHECK_LAUNCH("repack_conv_weight");
+  return GIC_OK;
+}
+
+int gic_conv2d(const void* in, const void* w, void* out, float* stats, int dtype, int N, int H, int W, int Cin, int Cout, int KH,
+               int KW, int stride, int pad, void* stream) {
+  GIC_CHECK_ARG(in && w && out, "conv2d: null pointer");
+  GIC_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "conv2d: bad dims");
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  GIC_CHECK_ARG(Ho > 0 && Wo > 0, "conv2d: empty output");
+  GemmDesc g;
+  g.A = in; g.B = w; g.C = out;
+  g.M = N * Ho * Wo; g.N = Cout; g.K = KH * KW * Cin;
+  g.lda = Cin; g.ldb = g.K; g.ldc = Cout;
+  g.in_dtype = dtype; g.out_dtype = dtype;
+  g.conv = 1; g.cH = H; g.cW = W; g.cCin = Cin; g.cHo = Ho; g.cWo = Wo; g.cKH = KH; g.cKW = KW; g.cStride = stride; g.cPad = pad;
+  g.epi = stats ? EPI_BNSTATS : EPI_PLAIN;
+  g.stats = stats;
+  return gemm(g, (hipStream_t)stream);
+}
+
+int gic_bn_act(const void* y, const float* stats, const float* gamma, const float* beta, const float* run_mean, const float* run_var,
+               const void* res, const float* res_stats, const float* res_gamma, const float* res_beta, const float* res_run_mean,
+               const float* res_run_var, float count, int relu, void* out, int dtype, int64_t rows, int C, void* stream) {
+  GIC_CHECK_ARG(y && out && gamma && beta && (stats || run_mean) && C % 4 == 0 && rows > 0 && count > 0, "bn_act: bad argument");
+  const BnSrc by = make_src(stats, gamma, beta, run_mean, run_var);
+  const BnSrc br = make_src(res_stats, res_gamma, res_beta, res_run_mean, res_run_var);
+  const long total = rows * (C / 4);
+  GIC_CHECK_ARG(((C / 4) & (C / 4 - 1)) == 0, "bn_act: C/4 must be a power of two (got C=%d)", C);
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL((bn_act_kernel<float>), dim3(grid_periodic(total, C / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)y, by, (const float*)res, br, 1.f / count, relu, (float*)out, (long)rows, C);
+  else
+    hipLaunchKernelGGL((bn_act_kernel<bf16_t>), dim3(grid_periodic(total, C / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, by, (const bf16_t*)res, br, 1.f / count, relu, (bf16_t*)out, (long)rows, C);
+  GIC_CHECK_LAUNCH("bn_act");
+  return GIC_OK;
+}
+
+int gic_bn_relu_maxpool(const void* y, const float* stats, const float* gamma, const float* beta, const float* run_mean,
+                        const float* run_var, float count, void* out, int dtype, int N, int H, int W, int C, void* stream) {
+  GIC_CHECK_ARG(y && out && gamma && beta && (stats || run_mean) && C % 4 == 0, "bn_relu_maxpool: bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const BnSrc by = make_src(stats, gamma, beta, run_mean, run_var);
+  const long total = (long)N * Ho * Wo * (C / 4);
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL((bn_relu_maxpool_kernel<float>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, (const float*)y, by, 1.f / count, (float*)out, N, H, W, C, Ho, Wo);
+  else
+    hipLaunchKernelGGL((bn_relu_maxpool_kernel<bf16_t>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, by, 1.f / count, (bf16_t*)out, N, H, W, C, Ho, Wo);
+  GIC_CHECK_LAUNCH("bn_relu_maxpool");
+  return GIC_OK;
+}
+
+int gic_avgpool(const void* x, void* out, int dtype, int N, int HW, int C, void* stream) {
+  GIC_CHECK_ARG(x && out && N > 0 && HW > 0 && C > 0, "avgpool: bad argument");
+  const long total = (long)N * C;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL((avgpool_kernel<float>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, N, HW, C);
+  else
+    hipLaunchKernelGGL((avgpool_kernel<bf16_t>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, N, HW, C);
+  GIC_CHECK_LAUNCH("avgpool");
+  return GIC_OK;
+}
+
+int gic_bn_running_update(const gic_bn_running_desc* table_dev, int nlayers, void* stream) {
+  GIC_CHECK_ARG(table_dev && nlayers > 0, "bn_running_update: bad argument");
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(nlayers), dim3(256), 0, (hipStream_t)stream, table_dev, nlayers);
+  GIC_CHECK_LAUNCH("bn_running_update");
+  return GIC_OK;
+}
+
+int gic_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int training,
+                 float momentum, float eps, float* y, float* xhat, float* invstd, int B, int E, void* stream) {
+  GIC_CHECK_ARG(x && gamma && beta && running_mean && running_var && y && xhat && invstd && B > 0 && E > 0, "bn1d_fwd: bad argument");
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(E, 256)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, running_mean, running_var,
+                     training, momentum, eps, y, xhat, invstd, B, E);
+  GIC_CHECK_LAUNCH("bn1d_fwd");
+  return GIC_OK;
+}
+
+int gic_bn1d_bwd(const float* dy, const float* xhat, const float* invstd, const float* gamma, int training, float* dx, float* dgamma,
+                 float* dbeta, int B, int E, void* stream) {
+  GIC_CHECK_ARG(dy && xhat && invstd && gamma && dx && dgamma && dbeta && B > 0 && E > 0, "bn1d_bwd: bad argument");
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(E, 256)), dim3(256), 0, (hipStream_t)stream, dy, xhat, invstd, gamma, training, dx,
+                     dgamma, dbeta, B, E);
+  GIC_CHECK_LAUNCH("bn1d_bwd");
+  return GIC_OK;
+}
+
+int gic_colsum(const void* A, int dtype, int64_t lda, int64_t rows, int64_t cols, float* out, int accumulate, void* stream) {
+  return colsum(A, dtype, lda, rows, cols, out, nullptr, accumulate, (hipStream_t)stream);
+}
+
+}  // extern "C"

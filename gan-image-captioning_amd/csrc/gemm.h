@@ -13,7 +13,7 @@
 
 namespace gic {
 
-enum GemmEpi { EPI_PLAIN = 0, EPI_HIGHWAY = 1 };
+enum GemmEpi { EPI_PLAIN = 0, EPI_HIGHWAY = 1, EPI_BNSTATS = 2 };
 
 struct GemmDesc {
   const void* A = nullptr;
@@ -34,6 +34,13 @@ struct GemmDesc {
   uint8_t* mask_out = nullptr; long ldmask_out = 0;   // keep mask actually used, written for backward (optional)
   float keep_scale = 1.f;                       // 1/(1-p) in train mode, 1 in eval
   int use_philox = 0; float drop_p = 0.f; uint64_t seed = 0, stream = 0;
+  // ---- implicit-GEMM convolution (conv != 0): A(m,k) is gathered from an NHWC activation `A`
+  //      [Nimg, cH, cW, cCin] with m = (n, ho, wo) and k = (r, s, c); M = Nimg*cHo*cWo, K = cKH*cKW*cCin;
+  //      B = weights [Cout, cKH, cKW, cCin] (k-contiguous).  Out-of-image taps read as zero.
+  int conv = 0;
+  int cH = 0, cW = 0, cCin = 0, cHo = 0, cWo = 0, cKH = 0, cKW = 0, cStride = 1, cPad = 0;
+  // ---- EPI_BNSTATS: C = result (+bias) and stats[n] += sum_m v, stats[N+n] += sum_m v^2 (f32 atomics)
+  float* stats = nullptr;
 };
 
 // Enqueue on `stream`. Returns GIC_OK or a negative Status (message via gic_last_error()).

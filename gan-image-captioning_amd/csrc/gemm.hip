@@ -29,8 +29,9 @@ typedef const __attribute__((address_space(1))) u32x4* gptr_u4;
 
 template <typename T> struct GlobalPtr { typedef const __attribute__((address_space(1))) T* type; };
 
-template <typename TI, typename TO, bool AKC, bool BKC, int BM, int BN, bool VEC, int EPI>
+template <typename TI, typename TO, bool AKC, bool BKC, int BM, int BN, bool VEC, int EPI, bool CONV>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k_tiles_per_split) {
+  static_assert(!CONV || (AKC && BKC && VEC), "the implicit-GEMM convolution loader is k-contiguous and vectorised");
   constexpr int SZ = sizeof(TI);
   constexpr int BK = 128 / SZ;          // K elements per tile
   constexpr int VE = 16 / SZ;           // elements per 16-byte chunk
@@ -74,6 +75,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
 
   u32x4 ra[CA], rb[CB];
 
+  // ---- implicit-GEMM convolution: per staged row (fixed per thread) the image and the top-left input pixel;
+  // per thread ONE running (r, s, c) decomposition of its k (all of a thread's chunks share kc = tid & 7).
+  long cv_base[CONV ? CA : 1];
+  int cv_hi0[CONV ? CA : 1], cv_wi0[CONV ? CA : 1];
+  int cv_r = 0, cv_s = 0, cv_c = 0;
+  if constexpr (CONV) {
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int m = bm0 + ((tid + i * 256) >> 3);
+      const int mm = m < M ? m : 0;
+      const int wo = mm % d.cWo, t = mm / d.cWo;
+      const int ho = t % d.cHo, n = t / d.cHo;
+      cv_hi0[i] = m < M ? ho * d.cStride - d.cPad : -(1 << 28);      // rows past M never validate
+      cv_wi0[i] = wo * d.cStride - d.cPad;
+      cv_base[i] = ((long)n * d.cH + cv_hi0[i]) * d.cW + cv_wi0[i];
+    }
+    const int k = blockIdx.y * k_tiles_per_split * BK + (tid & 7) * VE;
+    cv_c = k % d.cCin;
+    const int t = k / d.cCin;
+    cv_s = t % d.cKW;
+    cv_r = t / d.cKW;
+  }
+
   // global -> registers (VEC path).  Typed address_space(1) loads: a `cond ? *p : zero` on a generic pointer
   // makes the compiler select between the global address and a private zero and spill the staging registers.
   auto gload = [&](int kt) {
@@ -83,7 +107,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
       for (int i = 0; i < CA; ++i) {
         const int c = tid + i * 256;
         ra[i] = (u32x4){0u, 0u, 0u, 0u};
-        if constexpr (AKC) {
+        if constexpr (CONV) {
+          const int hi = cv_hi0[i] + cv_r, wi = cv_wi0[i] + cv_s;
+          if (cv_r < d.cKH && hi >= 0 && hi < d.cH && wi >= 0 && wi < d.cW)
+            ra[i] = *(gptr_u4)(A + (cv_base[i] + (long)cv_r * d.cW + cv_s) * d.cCin + cv_c);
+        } else if constexpr (AKC) {
           const int m = bm0 + (c >> 3), k = k0 + (c & 7) * VE;
           if (m < M && k < K) ra[i] = *(gptr_u4)(A + (long)m * lda + k);
         } else {
@@ -103,6 +131,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
           constexpr int CPR = BN / VE;
           const int k = k0 + c / CPR, n = bn0 + (c % CPR) * VE;
           if (k < K && n < N) rb[i] = *(gptr_u4)(B + (long)k * ldb + n);
+        }
+      }
+      if constexpr (CONV) {       // advance this thread's (r, s, c) by one K tile
+        cv_c += BK;
+        while (cv_c >= d.cCin) {
+          cv_c -= d.cCin;
+          if (++cv_s == d.cKW) { cv_s = 0; ++cv_r; }
         }
       }
     }
@@ -285,12 +320,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
           keep4[3] = Philox::u01(r3) >= d.drop_p ? 1.f : 0.f;
         }
       }
+      float st_s = 0.f, st_q = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = mb + r;
         if (m >= M) continue;
         float v = d.alpha * acc[i][j][r] + bias;
-        if constexpr (EPI == EPI_PLAIN) {
+        if constexpr (EPI == EPI_BNSTATS) {
+          C[(long)m * d.ldc + n] = from_f32<TO>(v);
+          st_s += v; st_q += v * v;
+        } else if constexpr (EPI == EPI_PLAIN) {
           const long o = (long)m * d.ldc + n;
           if constexpr (sizeof(TO) == 4) {
             if (split) { atomicAdd((float*)&C[o], v); continue; }
@@ -308,6 +347,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
           C[(long)m * d.ldc + n] = from_f32<TO>(y * keep * d.keep_scale);
         }
       }
+      if constexpr (EPI == EPI_BNSTATS) {
+        // column n lives in lanes {lr, lr+16, lr+32, lr+48}: fold the 4 row groups, one atomic pair per column
+        st_s += __shfl_xor(st_s, 16, 64); st_q += __shfl_xor(st_q, 16, 64);
+        st_s += __shfl_xor(st_s, 32, 64); st_q += __shfl_xor(st_q, 32, 64);
+        if (lg == 0) { atomicAdd(&d.stats[n], st_s); atomicAdd(&d.stats[N + n], st_q); }
+      }
     }
   }
 }
@@ -318,7 +363,7 @@ __global__ void zero2d_kernel(float* __restrict__ C, long ldc, int M, int N) {
     C[(i / N) * ldc + (i % N)] = 0.f;
 }
 
-template <typename TI, typename TO, bool AKC, bool BKC, int BM, int BN, bool VEC, int EPI>
+template <typename TI, typename TO, bool AKC, bool BKC, int BM, int BN, bool VEC, int EPI, bool CONV = false>
 int launch(const GemmDesc& d, hipStream_t stream) {
   constexpr int BK = 128 / (int)sizeof(TI);
   const int tiles = cdiv(d.M, BM) * cdiv(d.N, BN);
@@ -339,7 +384,7 @@ int launch(const GemmDesc& d, hipStream_t stream) {
     const int g = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
     hipLaunchKernelGGL(zero2d_kernel, dim3(g), dim3(256), 0, stream, (float*)d.C, d.ldc, d.M, d.N);
   }
-  hipLaunchKernelGGL((gemm_kernel<TI, TO, AKC, BKC, BM, BN, VEC, EPI>), dim3(tiles, splits), dim3(256), 0, stream, d, per);
+  hipLaunchKernelGGL((gemm_kernel<TI, TO, AKC, BKC, BM, BN, VEC, EPI, CONV>), dim3(tiles, splits), dim3(256), 0, stream, d, per);
   GIC_CHECK_LAUNCH("gemm");
   return GIC_OK;
 }
@@ -368,8 +413,24 @@ int pick_layout(const GemmDesc& d, bool vec, hipStream_t stream) {
   return GIC_ERR_UNSUPPORTED;
 }
 
+template <typename TI, typename TO, int EPI>
+int pick_conv(const GemmDesc& d, hipStream_t stream) {
+  const long big_tiles = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
+  if (big_tiles >= 192 && d.N >= 128) return launch<TI, TO, true, true, 128, 128, true, EPI, true>(d, stream);
+  return launch<TI, TO, true, true, 64, 64, true, EPI, true>(d, stream);
+}
+
 template <typename TI, typename TO>
 int pick_epi(const GemmDesc& d, bool vec, hipStream_t stream) {
+  if (d.conv) {
+    if (!vec || !d.a_kc || !d.b_kc) { set_last_error("gemm: convolution needs 16-B aligned NHWC / KRSC operands"); return GIC_ERR_UNSUPPORTED; }
+    if constexpr (sizeof(TI) == sizeof(TO)) {
+      if (d.epi == EPI_BNSTATS) return pick_conv<TI, TO, EPI_BNSTATS>(d, stream);
+      if (d.epi == EPI_PLAIN) return pick_conv<TI, TO, EPI_PLAIN>(d, stream);
+    }
+    set_last_error("gemm: unsupported convolution epilogue / dtype");
+    return GIC_ERR_UNSUPPORTED;
+  }
   if (d.epi == EPI_PLAIN) return pick_layout<TI, TO, EPI_PLAIN>(d, vec, stream);
   if (d.epi == EPI_HIGHWAY) return pick_layout<TI, TO, EPI_HIGHWAY>(d, vec, stream);
   set_last_error("gemm: unknown epilogue %d", d.epi);
@@ -388,6 +449,13 @@ int gemm(const GemmDesc& d, hipStream_t stream) {
   const int sz = dtype_size(d.in_dtype);
   const int ve = 16 / sz;
   bool vec = aligned16(d.A) && aligned16(d.B) && (d.lda % ve == 0) && (d.ldb % ve == 0);
+  if (d.conv) {
+    // a 16-B chunk holds `ve` consecutive k = channels of one tap, or (pre-padded input, pad == 0) whole adjacent taps of one row
+    const bool chunk_ok = (d.cCin % ve == 0) || (d.cPad == 0 && ve % d.cCin == 0 && (d.cKW * d.cCin) % ve == 0);
+    GIC_CHECK_ARG(chunk_ok && d.K == d.cKH * d.cKW * d.cCin && d.K % ve == 0, "gemm: conv needs Cin %% %d == 0 (or a pre-padded NHWC4 stem) and K = KH*KW*Cin", ve);
+    GIC_CHECK_ARG(d.epi != EPI_BNSTATS || d.stats, "gemm: EPI_BNSTATS needs a stats buffer");
+    vec = aligned16(d.A) && aligned16(d.B) && (d.ldb % ve == 0);
+  }
   // k-contiguous operands: K must be a whole number of 16-B chunks (callers zero-pad K).  m/n-contiguous
   // operands: a tail chunk reads into the row's padding (ld % ve == 0 >= M) and only feeds rows that are
   // never stored, so no condition on M / N.

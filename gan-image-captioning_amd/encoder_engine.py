@@ -1,17 +1,309 @@
-"""Host wrappers of the encoder kernels (image trunk + Linear/BatchNorm1d head).  Filled in with the
-trunk kernels; until then the conditional path raises instead of computing anywhere else."""
+"""Host side of the encoder kernels: execution plan of the ResNet trunk (buffers, packed weights,
+BatchNorm statistics arena) and the Linear + BatchNorm1d head, all through the C ABI.
+
+Trunk dataflow per convolution (NHWC, compute dtype):
+    y = conv(x)            gic_conv2d: implicit GEMM on MFMA, BatchNorm sums reduced in the epilogue
+    z = relu(bn(y) [+ r])  gic_bn_act: one read of y (+ residual) and one write
+The stem fuses bn + relu + 3x3/2 max-pool (gic_bn_relu_maxpool).  All BatchNorm sums of one forward live
+in ONE f32 arena that is zeroed with a single fill and consumed by ONE running-statistics launch.
+"""
 from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from . import engine
+from .engine import ptr, stream_ptr
+
+AVAILABLE = True
+
+
+def _check(status, what):
+    L.check(status, what)
+
+
+class _ConvStep:
+    __slots__ = ("conv", "bn", "cin", "cout", "k", "stride", "pad", "stats_off", "w", "name")
+
+    def __init__(self, name, conv, bn):
+        self.name, self.conv, self.bn = name, conv, bn
+        self.cin, self.cout, self.k, self.stride, self.pad = conv.cin, conv.cout, conv.k, conv.stride, conv.pad
+        self.stats_off = 0
+        self.w = None
 
 
 class TrunkPlan:
-    def __init__(self, trunk, dtype):
-        self.dtype = dtype
-        raise NotImplementedError("encoder trunk kernels are not built yet: use --conditional-gan 0")
+    def __init__(self, trunk, dtype: int):
+        self.trunk, self.dtype = trunk, dtype
+        self.act = engine.TORCH_DTYPE[dtype]
+        self.stem = _ConvStep("0", getattr(trunk, "0"), getattr(trunk, "1"))
+        self.blocks: List[dict] = []
+        for si, stage in enumerate(trunk.stages()):
+            for bi, blk in enumerate(stage):
+                p = f"{4 + si}.{bi}."
+                b = {"kind": blk.kind, "c1": _ConvStep(p + "conv1", blk.conv1, blk.bn1), "c2": _ConvStep(p + "conv2", blk.conv2, blk.bn2),
+                     "c3": _ConvStep(p + "conv3", blk.conv3, blk.bn3) if blk.kind == "bottleneck" else None,
+                     "ds": _ConvStep(p + "downsample.0", blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None}
+                self.blocks.append(b)
+        self.steps: List[_ConvStep] = [self.stem]
+        for b in self.blocks:
+            self.steps += [s for s in (b["c1"], b["c2"], b["c3"], b["ds"]) if s is not None]
+        off = 0
+        for s in self.steps:
+            s.stats_off = off
+            off += 2 * s.cout
+        self.stats_len = off
+        self._wkey = None
+        self._bufs: Dict[Tuple[int, int], dict] = {}
+        self.pending_tracked = 0
+
+    def sync_counters(self) -> None:
+        """Fold the forward count into every BatchNorm's ``num_batches_tracked`` buffer (kept off the hot path)."""
+        if self.pending_tracked:
+            for s in self.steps:
+                s.bn.num_batches_tracked += self.pending_tracked
+            self.pending_tracked = 0
+
+    # ---------------------------------------------------------------- weights (frozen: packed once per version)
+    def _pack_weights(self, dev) -> None:
+        key = tuple((s.conv.weight.data_ptr(), s.conv.weight._version) for s in self.steps)
+        if key == self._wkey:
+            return
+        lib = L.load()
+        for s in self.steps:
+            w = s.conv.weight.detach()
+            engine.require_gpu(w)
+            if s is self.stem:
+                cinp, kwp = 4, 8                       # [64,7,8,4]: the stem reads a zero-bordered NHWC4 image
+            else:
+                cinp, kwp = s.cin, s.k
+            s.w = torch.empty(s.cout, s.k, kwp, cinp, device=dev, dtype=self.act)
+            _check(lib.gic_repack_conv_weight(ptr(w.contiguous()), ptr(s.w), self.dtype, s.cout, s.cin, s.k, s.k, cinp, kwp, stream_ptr()),
+                   "gic_repack_conv_weight")
+        self._wkey = key
+
+    # ---------------------------------------------------------------- buffers for one (batch, image size)
+    def _buffers(self, N: int, S: int, dev) -> dict:
+        key = (N, S)
+        if key in self._bufs:
+            return self._bufs[key]
+        act = self.act
+        b: dict = {"stats": torch.zeros(self.stats_len, device=dev, dtype=torch.float32)}
+        b["xin"] = torch.empty(N, S + 6, S + 6, 4, device=dev, dtype=act)
+        h = (S + 6 - 7) // 2 + 1
+        b["y0"] = torch.empty(N, h, h, 64, device=dev, dtype=act)
+        hp = (h + 2 - 3) // 2 + 1
+        b["x0"] = torch.empty(N, hp, hp, 64, device=dev, dtype=act)
+        rows = {self.stem.name: N * h * h}
+        cur = hp
+        blocks = []
+        for blk in self.blocks:
+            c1, c2, c3, ds = blk["c1"], blk["c2"], blk["c3"], blk["ds"]
+            e: dict = {"hin": cur}
+            if blk["kind"] == "basic":
+                ho = (cur + 2 - 3) // c1.stride + 1
+                e["y1"] = torch.empty(N, ho, ho, c1.cout, device=dev, dtype=act); e["z1"] = torch.empty_like(e["y1"])
+                e["y2"] = torch.empty(N, ho, ho, c2.cout, device=dev, dtype=act)
+                rows[c1.name] = rows[c2.name] = N * ho * ho
+                cout = c2.cout
+            else:
+                e["y1"] = torch.empty(N, cur, cur, c1.cout, device=dev, dtype=act); e["z1"] = torch.empty_like(e["y1"])
+                rows[c1.name] = N * cur * cur
+                ho = (cur + 2 - 3) // c2.stride + 1
+                e["y2"] = torch.empty(N, ho, ho, c2.cout, device=dev, dtype=act); e["z2"] = torch.empty_like(e["y2"])
+                e["y3"] = torch.empty(N, ho, ho, c3.cout, device=dev, dtype=act)
+                rows[c2.name] = rows[c3.name] = N * ho * ho
+                cout = c3.cout
+            if ds is not None:
+                e["yd"] = torch.empty(N, ho, ho, ds.cout, device=dev, dtype=act)
+                rows[ds.name] = N * ho * ho
+            e["out"] = torch.empty(N, ho, ho, cout, device=dev, dtype=act)
+            e["hout"] = ho
+            blocks.append(e)
+            cur = ho
+        b["blocks"] = blocks
+        b["feat"] = torch.empty(N, self.trunk.out_features, device=dev, dtype=act)
+        b["rows"] = rows
+        # device table for the one-launch running-statistics update
+        table = (L.BnRunningDesc * len(self.steps))()
+        for i, s in enumerate(self.steps):
+            table[i].stats = b["stats"].data_ptr() + 4 * s.stats_off
+            table[i].running_mean = s.bn.running_mean.data_ptr()
+            table[i].running_var = s.bn.running_var.data_ptr()
+            table[i].count = float(rows[s.name])
+            table[i].momentum = float(s.bn.momentum)
+            table[i].C = s.cout
+        raw = bytes(table)
+        b["table"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self._bufs[key] = b
+        return b
+
+    # ---------------------------------------------------------------- kernels
+    def _conv(self, s: _ConvStep, x: torch.Tensor, y: torch.Tensor, stats: Optional[torch.Tensor], N, H, W, cin=None, kw=None, pad=None):
+        st = None if stats is None else stats.data_ptr() + 4 * s.stats_off
+        _check(L.load().gic_conv2d(ptr(x), ptr(s.w), ptr(y), st, self.dtype, N, H, W, cin if cin is not None else s.cin, s.cout, s.k,
+                                   kw if kw is not None else s.k, s.stride, pad if pad is not None else s.pad, stream_ptr()), "gic_conv2d " + s.name)
+
+    def _bn_args(self, s: Optional[_ConvStep], stats: Optional[torch.Tensor], training: bool):
+        """(stats, gamma, beta, run_mean, run_var) pointers of one BatchNorm; all None for 'no BN'."""
+        if s is None:
+            return (None,) * 5
+        g, b = ptr(s.bn.weight.detach()), ptr(s.bn.bias.detach())
+        if training:
+            return (stats.data_ptr() + 4 * s.stats_off, g, b, None, None)
+        return (None, g, b, ptr(s.bn.running_mean), ptr(s.bn.running_var))
+
+    def _bn_act(self, s, y, out, stats, training, rows, relu=True, res=None, res_step=None):
+        a = self._bn_args(s, stats, training)
+        r = self._bn_args(res_step, stats, training)
+        _check(L.load().gic_bn_act(ptr(y), *a, ptr(res), *r, float(rows), int(relu), ptr(out), self.dtype, rows, s.cout, stream_ptr()),
+               "gic_bn_act " + s.name)
+
+    def forward(self, images: torch.Tensor, training: bool) -> torch.Tensor:
+        """images f32 [N,3,S,S] (NCHW, as the reference's collate_fn delivers them) -> features act [N, C]."""
+        engine.require_gpu(images)
+        if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != images.shape[3] or images.dtype != torch.float32:
+            raise ValueError(f"images must be float32 [N,3,S,S], got {tuple(images.shape)} {images.dtype}")
+        N, S = images.shape[0], images.shape[2]
+        if S % 2:
+            raise ValueError("image size must be even")
+        dev = images.device
+        lib = L.load()
+        self._pack_weights(dev)
+        b = self._buffers(N, S, dev)
+        stats = b["stats"] if training else None
+        if training:
+            b["stats"].zero_()
+        rows = b["rows"]
+        # stem: 7x7/2 on the zero-bordered NHWC4 image (window [7 x 8 x 4], no bounds checks), bn+relu+maxpool
+        _check(lib.gic_pack_image(ptr(images.contiguous()), ptr(b["xin"]), self.dtype, N, S, 3, S + 6, stream_ptr()), "gic_pack_image")
+        self._conv(self.stem, b["xin"], b["y0"], stats, N, S + 6, S + 6, cin=4, kw=8, pad=0)
+        h = b["y0"].shape[1]
+        a = self._bn_args(self.stem, stats, training)
+        _check(lib.gic_bn_relu_maxpool(ptr(b["y0"]), *a, float(rows[self.stem.name]), ptr(b["x0"]), self.dtype, N, h, h, 64, stream_ptr()),
+               "gic_bn_relu_maxpool")
+        x = b["x0"]
+        for blk, e in zip(self.blocks, b["blocks"]):
+            c1, c2, c3, ds = blk["c1"], blk["c2"], blk["c3"], blk["ds"]
+            hin, ho = e["hin"], e["hout"]
+            if blk["kind"] == "basic":
+                self._conv(c1, x, e["y1"], stats, N, hin, hin)
+                self._bn_act(c1, e["y1"], e["z1"], stats, training, rows[c1.name])
+                self._conv(c2, e["z1"], e["y2"], stats, N, ho, ho)
+                last, ylast = c2, e["y2"]
+            else:
+                self._conv(c1, x, e["y1"], stats, N, hin, hin)
+                self._bn_act(c1, e["y1"], e["z1"], stats, training, rows[c1.name])
+                self._conv(c2, e["z1"], e["y2"], stats, N, hin, hin)
+                self._bn_act(c2, e["y2"], e["z2"], stats, training, rows[c2.name])
+                self._conv(c3, e["z2"], e["y3"], stats, N, ho, ho)
+                last, ylast = c3, e["y3"]
+            if ds is not None:
+                self._conv(ds, x, e["yd"], stats, N, hin, hin)
+                self._bn_act(last, ylast, e["out"], stats, training, rows[last.name], res=e["yd"], res_step=ds)
+            else:
+                self._bn_act(last, ylast, e["out"], stats, training, rows[last.name], res=x, res_step=None)
+            x = e["out"]
+        ho = x.shape[1]
+        _check(lib.gic_avgpool(ptr(x), ptr(b["feat"]), self.dtype, N, ho * ho, x.shape[3], stream_ptr()), "gic_avgpool")
+        if training:
+            _check(lib.gic_bn_running_update(ptr(b["table"]), len(self.steps), stream_ptr()), "gic_bn_running_update")
+            self.pending_tracked += 1          # num_batches_tracked buffers are brought up to date by sync_counters()
+        return b["feat"]
+
+    # ---------------------------------------------------------------- measurement helper for bench.py
+    def conv_shapes(self, N: int, S: int):
+        """[(step, input tensor, output tensor, H, W, conv kwargs, macs)] in execution order."""
+        b = self._buffers(N, S, self.stem.conv.weight.device)
+        out = [(self.stem, b["xin"], b["y0"], S + 6, S + 6, dict(cin=4, kw=8, pad=0), b["y0"].shape[1] ** 2 * N * 64 * 147)]
+        x = b["x0"]
+        for blk, e in zip(self.blocks, b["blocks"]):
+            c1, c2, c3, ds = blk["c1"], blk["c2"], blk["c3"], blk["ds"]
+            hin, ho = e["hin"], e["hout"]
+            seq = [(c1, x, e["y1"], hin), (c2, e["z1"], e["y2"], ho if blk["kind"] == "basic" else hin)]
+            if c3 is not None:
+                seq.append((c3, e["z2"], e["y3"], ho))
+            if ds is not None:
+                seq.append((ds, x, e["yd"], hin))
+            for s, xi, yo, hh in seq:
+                out.append((s, xi, yo, hh, hh, {}, yo.shape[0] * yo.shape[1] * yo.shape[2] * s.cout * s.cin * s.k * s.k))
+            x = e["out"]
+        return out
 
 
-def head_fwd(*a, **k):
-    raise NotImplementedError("encoder head kernels are not built yet: use --conditional-gan 0")
+# ------------------------------------------------------------------------------------------ encoder head
+def head_fwd(dtype, feat, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, out=None):
+    """Linear(feat -> E) + BatchNorm1d on [B,E] (generator.py:24).  feat: act or f32 [B,F].  Returns (out f32 [B,E], saved)."""
+    engine.require_gpu(feat, weight, bias, gamma, beta)
+    act = engine.TORCH_DTYPE[dtype]
+    B, F = feat.shape
+    E = weight.shape[0]
+    dev = feat.device
+    if feat.dtype != act:
+        f2 = torch.empty(B, F, device=dev, dtype=act)
+        engine.cast2d(feat.contiguous(), f2, B, F, F, F)
+        feat = f2
+    feat = feat.contiguous()
+    wsh = weight
+    if dtype != L.F32:
+        wsh = torch.empty(E, F, device=dev, dtype=act)
+        engine.cast2d(weight, wsh, E, F, F, F)
+    y = torch.empty(B, E, device=dev, dtype=torch.float32)
+    engine.gemm(feat, wsh, y, B, E, F, F, F, E, bias=bias)
+    out = out if out is not None else torch.empty(B, E, device=dev, dtype=torch.float32)
+    xhat = torch.empty(B, E, device=dev, dtype=torch.float32)
+    invstd = torch.empty(E, device=dev, dtype=torch.float32)
+    L.check(L.load().gic_bn1d_fwd(ptr(y), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), int(bool(training)), float(momentum),
+                                  float(eps), ptr(out), ptr(xhat), ptr(invstd), B, E, stream_ptr()), "gic_bn1d_fwd")
+    return out, (feat, xhat, invstd, bool(training))
 
 
-def head_bwd(*a, **k):
-    raise NotImplementedError("encoder head kernels are not built yet: use --conditional-gan 0")
+def head_bwd(dtype, saved, weight, gamma, d_out, grads=None):
+    """Returns (d_weight [E,F], d_bias [E], d_gamma [E], d_beta [E]); the trunk is frozen so no d_feat."""
+    feat, xhat, invstd, training = saved
+    act = engine.TORCH_DTYPE[dtype]
+    B, F = feat.shape
+    E = weight.shape[0]
+    dev = feat.device
+    d_out = d_out.contiguous().float()
+    dw, db, dg, dbt = grads if grads is not None else (torch.empty(E, F, device=dev), torch.empty(E, device=dev),
+                                                       torch.empty(E, device=dev), torch.empty(E, device=dev))
+    dy = torch.empty(B, E, device=dev, dtype=torch.float32)
+    L.check(L.load().gic_bn1d_bwd(ptr(d_out), ptr(xhat), ptr(invstd), ptr(gamma), int(training), ptr(dy), ptr(dg), ptr(dbt), B, E,
+                                  stream_ptr()), "gic_bn1d_bwd")
+    dya = dy
+    if dtype != L.F32:
+        dya = torch.empty(B, E, device=dev, dtype=act)
+        engine.cast2d(dy, dya, B, E, E, E)
+    engine.gemm(dya, feat, dw, E, F, B, E, F, F, a_kc=False, b_kc=False)          # dW = dy^T feat
+    L.check(L.load().gic_colsum(ptr(dy), L.F32, E, B, E, ptr(db), 0, stream_ptr()), "gic_colsum")
+    return dw, db, dg, dbt
+
+
+def roofline_probe(encoder, args, event_time_ms, peak_tflops):
+    """Time every convolution of the trunk with its step shapes and report the one that dominates."""
+    plan = encoder.resnet._plan
+    N, S = args.adv_train_batch_size, args.image_size
+    stream = torch.cuda.current_stream()
+    best = None
+    total_ms, total_flops = 0.0, 0.0
+    seen = {}
+    for s, xi, yo, H, W, kw, macs in plan.conv_shapes(N, S):
+        key = (s.cin, s.cout, s.k, s.stride, H)
+        if key not in seen:
+            seen[key] = [event_time_ms(lambda: plan._conv(s, xi, yo, None, N, H, W, **kw), 5, stream), 0, macs, s.name]
+        seen[key][1] += 1
+    for key, (ms, count, macs, name) in seen.items():
+        total_ms += ms * count
+        total_flops += 2.0 * macs * count
+        if best is None or ms * count > best[0] * best[1]:
+            best = (ms, count, macs, name, key)
+    ms, count, macs, name, key = best
+    achieved = 2.0 * macs / (ms * 1e-3) / 1e12
+    return {"kernel": f"gemm_kernel<CONV> implicit-GEMM conv {name} (Cin={key[0]},Cout={key[1]},k={key[2]},stride={key[3]},H={key[4]}) x{count}/step",
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(achieved / peak_tflops, 4),
+            "traffic": None, "ms_per_launch": round(ms, 5),
+            "all_convs": {"ms_per_step": round(total_ms, 4), "tflops": round(total_flops / (total_ms * 1e-3) / 1e12, 2)}}

@@ -202,11 +202,25 @@ class Encoder(nn.Module):
         with torch.no_grad():                                        # generator.py:21-22
             feats = self.resnet(images, _compute_dtype(self.args))
         feats = feats.reshape(feats.size(0), -1)
-        if self.training:
-            self.bn.num_batches_tracked += 1
         return _EncoderHeadFn.apply(_compute_dtype(self.args), self.training, self.bn.momentum, self.bn.eps, feats,
                                     self.linear.weight, self.linear.bias, self.bn.weight, self.bn.bias,
                                     self.bn.running_mean, self.bn.running_var)
+
+    # ---- direct (no autograd) forms used by the fused step driver
+    def forward_fused(self, images, training: bool):
+        dt = _compute_dtype(self.args)
+        feats = self.resnet(images, dt, training)
+        out, self._saved = encoder_head_fwd(dt, feats, self.linear.weight.detach(), self.linear.bias.detach(),
+                                            self.bn.weight.detach(), self.bn.bias.detach(), self.bn.running_mean,
+                                            self.bn.running_var, training, self.bn.momentum, self.bn.eps)
+        return out
+
+    def backward_fused(self, d_feat):
+        """Gradients of the head into the .grad views of its four parameters (the trunk is frozen)."""
+        grads = (self.linear.weight.grad, self.linear.bias.grad, self.bn.weight.grad, self.bn.bias.grad)
+        encoder_head_bwd(_compute_dtype(self.args), self._saved, self.linear.weight.detach(), self.bn.weight.detach(), d_feat,
+                         grads=grads)
+        self._saved = None
 
 
 class Generator(nn.Module):

@@ -86,11 +86,16 @@ class ResNetTrunk(nn.Module):
     def stages(self) -> List[nn.Sequential]:
         return [getattr(self, str(i)) for i in (4, 5, 6, 7)]
 
-    def forward(self, images: torch.Tensor, dtype: int) -> torch.Tensor:
+    def forward(self, images: torch.Tensor, dtype: int, training=None) -> torch.Tensor:
         from . import encoder_engine
         if self._plan is None or self._plan.dtype != dtype:
             self._plan = encoder_engine.TrunkPlan(self, dtype)
-        return self._plan.forward(images, self.training)
+        return self._plan.forward(images, self.training if training is None else training)
+
+    def state_dict(self, *a, **k):
+        if self._plan is not None:
+            self._plan.sync_counters()
+        return super().state_dict(*a, **k)
 
 
 def encoder_head_fwd(dtype, feat, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps):
@@ -98,6 +103,6 @@ def encoder_head_fwd(dtype, feat, weight, bias, gamma, beta, running_mean, runni
     return encoder_engine.head_fwd(dtype, feat, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps)
 
 
-def encoder_head_bwd(dtype, saved, weight, gamma, d_out):
+def encoder_head_bwd(dtype, saved, weight, gamma, d_out, grads=None):
     from . import encoder_engine
-    return encoder_engine.head_bwd(dtype, saved, weight, gamma, d_out)
+    return encoder_engine.head_bwd(dtype, saved, weight, gamma, d_out, grads=grads)

@@ -207,6 +207,50 @@ int gic_disc_bwd(const gic_disc_dims* dims, const gic_disc_params* params, const
                  int accumulate, void* d_inp, int64_t ld_dinp, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Encoder (src/generator.py:8-25): ResNet trunk forward (frozen, BatchNorm on batch statistics) and the trainable
+ * Linear + BatchNorm1d(momentum=0.01) head.  Activations are NHWC in the compute dtype ("act").
+ */
+/* NCHW f32 [N,3,S,S] -> zero-bordered NHWC4 act [N, S+2*pad, Wp, 4] (channel 3 = 0); Wp >= S+2*pad. */
+int gic_pack_image(const float* nchw, void* out, int dtype, int N, int S, int pad, int Wp, void* stream);
+/* conv weight [Cout,Cin,KH,KW] f32 -> act [Cout,KH,KW_pad,Cin_pad] (zero padded). */
+int gic_repack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cin_pad, int KW_pad,
+                           void* stream);
+/* Implicit-GEMM convolution on MFMA: in act [N,H,W,Cin], w act [Cout,KH,KW,Cin], out act [N,Ho,Wo,Cout].  stats (optional,
+ * f32 [2*Cout], accumulated with atomics: the caller zeroes it): per-channel sum and sum of squares of the f32 results =
+ * the batch statistics nn.BatchNorm2d needs in train mode.  Replaces nn.Conv2d of the torchvision trunk (generator.py:12-14,22). */
+int gic_conv2d(const void* in, const void* w, void* out, float* stats, int dtype, int N, int H, int W, int Cin, int Cout,
+               int KH, int KW, int stride, int pad, void* stream);
+/* out = [relu]( bn(y) + (res ? bn_res(res) : 0) ) over rows x C.  A BatchNorm takes its mean/var from `stats` (raw sums over
+ * `count` rows; train mode) or from run_mean/run_var (eval mode); res_gamma == NULL -> the residual is added as is. */
+int gic_bn_act(const void* y, const float* stats, const float* gamma, const float* beta, const float* run_mean,
+               const float* run_var, const void* res, const float* res_stats, const float* res_gamma, const float* res_beta,
+               const float* res_run_mean, const float* res_run_var, float count, int relu, void* out, int dtype, int64_t rows,
+               int C, void* stream);
+/* Stem: relu(bn(y)) then 3x3 / stride 2 / pad 1 max-pool.  y act [N,H,W,C] -> out act [N,(H+1)/2,(W+1)/2,C]. */
+int gic_bn_relu_maxpool(const void* y, const float* stats, const float* gamma, const float* beta, const float* run_mean,
+                        const float* run_var, float count, void* out, int dtype, int N, int H, int W, int C, void* stream);
+/* Global average pool: x act [N,HW,C] -> out act [N,C]. */
+int gic_avgpool(const void* x, void* out, int dtype, int N, int HW, int C, void* stream);
+/* Running mean/var of every trunk BatchNorm2d in one launch; `table_dev` is a DEVICE array built once by the caller. */
+typedef struct gic_bn_running_desc {
+  const float* stats;      /* [2C] raw sums of this step */
+  float* running_mean;     /* [C] */
+  float* running_var;      /* [C] */
+  float count;             /* rows the sums were taken over */
+  float momentum;
+  int32_t C;
+  int32_t pad_;
+} gic_bn_running_desc;
+int gic_bn_running_update(const gic_bn_running_desc* table_dev, int nlayers, void* stream);
+/* nn.BatchNorm1d over the batch axis of x [B,E] (generator.py:16,24) forward / backward. */
+int gic_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int training,
+                 float momentum, float eps, float* y, float* xhat, float* invstd, int B, int E, void* stream);
+int gic_bn1d_bwd(const float* dy, const float* xhat, const float* invstd, const float* gamma, int training, float* dx,
+                 float* dgamma, float* dbeta, int B, int E, void* stream);
+/* out[c] (+)= sum_r A[r*lda + c] (bias gradients). */
+int gic_colsum(const void* A, int dtype, int64_t lda, int64_t rows, int64_t cols, float* out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * get_losses (src/utils.py:10-53): losses[0]=g_loss, losses[1]=d_loss (device scalars) and, when the
  * d_* pointers are non-NULL, the gradients of d_loss w.r.t. (d_real, d_fake) and of g_loss w.r.t.
  * (g_out, and for rsgan d_real/d_fake through dg_real/dg_fake).

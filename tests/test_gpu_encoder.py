@@ -1,0 +1,221 @@
+"""GPU parity of the image encoder (trunk convolutions on MFMA, BatchNorm on batch statistics, pooling, the
+Linear+BatchNorm1d head) against the CPU oracle (oracle/cpu_encoder.py; PARITY UNPINNED w.r.t. the reference
+because torchvision is absent - see its header) and, for the head, against the golden vectors produced with
+the reference's own nn.Linear / nn.BatchNorm1d(momentum=0.01) composition (tiny_cgan_head).
+
+fp32 mode: activations rtol 1e-3 of the tensor's max (53 stacked BatchNorms amplify fp32 reduction-order noise);
+bf16 mode: relative L2 error reported, <= 5e-2.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cpu_encoder as OE
+from oracle import cpu_step as O
+from tests.golden_io import Golden
+from tests.gpu_util import close, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _lib():
+    from gan_image_captioning_amd import _lib as L
+    return L
+
+
+def conv_hip(x_nchw, w, stride, pad, dtype, dev, want_stats=True):
+    """x [N,C,H,W] f32 CPU, w [Co,Ci,k,k] -> (y NCHW f32 cpu, stats)"""
+    from gan_image_captioning_amd import engine
+    L = _lib()
+    act = engine.TORCH_DTYPE[dtype]
+    N, C, H, W = x_nchw.shape
+    Co, _, k, _ = w.shape
+    xh = x_nchw.permute(0, 2, 3, 1).contiguous().to(dev).to(act)
+    wp = torch.empty(Co, k, k, C, device=dev, dtype=act)
+    L.check(L.load().gic_repack_conv_weight(w.to(dev).contiguous().data_ptr(), wp.data_ptr(), dtype, Co, C, k, k, C, k, engine.stream_ptr()), "repack")
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.empty(N, Ho, Wo, Co, device=dev, dtype=act)
+    stats = torch.zeros(2 * Co, device=dev)
+    L.check(L.load().gic_conv2d(xh.data_ptr(), wp.data_ptr(), y.data_ptr(), stats.data_ptr() if want_stats else None, dtype,
+                                N, H, W, C, Co, k, k, stride, pad, engine.stream_ptr()), "conv2d")
+    torch.cuda.synchronize()
+    return y.float().cpu().permute(0, 3, 1, 2), stats.cpu()
+
+
+CONV_CASES = [  # (N, Cin, H, Cout, k, stride, pad)
+    (2, 64, 16, 64, 3, 1, 1), (2, 64, 16, 128, 3, 2, 1), (3, 64, 8, 256, 1, 1, 0), (2, 128, 8, 64, 1, 2, 0),
+    (1, 256, 7, 512, 3, 1, 1), (4, 64, 56, 64, 3, 1, 1), (2, 512, 4, 2048, 1, 1, 0), (2, 8, 10, 24, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_matches_torch(dev, case, dtype):
+    N, Ci, H, Co, k, st, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, H, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) * 0.1
+    if dtype == 1:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    want = F.conv2d(x.double(), w.double(), None, st, pad)
+    y, stats = conv_hip(x, w, st, pad, dtype, dev)
+    tol = 2e-5 if dtype == 0 else 8e-3
+    err = float((y.double() - want).abs().max() / want.abs().max())
+    assert err < tol * max(1.0, (Ci * k * k / 64) ** 0.5), f"conv {case} dtype {dtype}: rel max err {err}"
+    rows = want.shape[0] * want.shape[2] * want.shape[3]
+    s1 = want.sum((0, 2, 3))
+    s2 = (want ** 2).sum((0, 2, 3))
+    close(stats[:Co], s1, rtol=1e-3, atol_scale=1e-4 * rows ** 0.5, what="bn sum")
+    close(stats[Co:], s2, rtol=1e-3, what="bn sumsq")
+
+
+@pytest.mark.parametrize("arch,S,N", [("resnet18", 64, 4), ("resnet50", 64, 2), ("resnet18", 96, 2)])
+def test_trunk_forward_f32_matches_oracle(dev, arch, S, N):
+    from gan_image_captioning_amd.trunk import ResNetTrunk
+    g = torch.Generator().manual_seed(7)
+    tp = OE.make_trunk_params(arch, g)
+    images = torch.randn(N, 3, S, S, generator=g)
+    running = {}
+    for name, _ci, co, *_ in OE.layer_specs(arch):
+        b = "encoder.resnet." + OE.bn_name(name)
+        running[b + ".running_mean"] = torch.zeros(co)
+        running[b + ".running_var"] = torch.ones(co)
+    taps = {}
+    want = OE.trunk_forward(tp, images, arch, training=True, running=running, taps=taps)
+    trunk = ResNetTrunk(arch)
+    trunk.load_state_dict({k[len("encoder.resnet."):]: v for k, v in tp.items()}, strict=False)
+    trunk = trunk.to(dev).train()
+    feat = trunk(images.to(dev), 0)
+    torch.cuda.synchronize()
+    close(feat, want, rtol=2e-3, atol_scale=2e-3, what=f"{arch} features")
+    # intermediate activation after the stem and the first stage
+    plan = trunk._plan
+    b = plan._bufs[(N, S)]
+    close(b["x0"].permute(0, 3, 1, 2), taps["stem"], rtol=1e-3, atol_scale=1e-4, what="stem output")
+    nb0 = len(trunk.stages()[0])
+    close(b["blocks"][nb0 - 1]["out"].permute(0, 3, 1, 2), taps["stage0"], rtol=1e-3, atol_scale=5e-4, what="stage0 output")
+    # running statistics (side effect of train-mode BatchNorm)
+    sd = trunk.state_dict()
+    close(sd["1.running_mean"], running["encoder.resnet.1.running_mean"], rtol=1e-3, atol_scale=1e-4, what="stem running_mean")
+    close(sd["1.running_var"], running["encoder.resnet.1.running_var"], rtol=1e-3, atol_scale=1e-4, what="stem running_var")
+    assert int(sd["1.num_batches_tracked"]) == 1
+    # eval mode uses the running statistics
+    trunk.eval()
+    want_eval = OE.trunk_forward(tp, images, arch, training=False, running=running)
+    feat_eval = trunk(images.to(dev), 0)
+    torch.cuda.synchronize()
+    close(feat_eval, want_eval, rtol=2e-3, atol_scale=2e-3, what="eval features")
+
+
+def test_trunk_forward_bf16_close(dev):
+    from gan_image_captioning_amd.trunk import ResNetTrunk
+    g = torch.Generator().manual_seed(8)
+    tp = OE.make_trunk_params("resnet50", g)
+    images = torch.randn(4, 3, 64, 64, generator=g)
+    want = OE.trunk_forward(tp, images, "resnet50")
+    trunk = ResNetTrunk("resnet50")
+    trunk.load_state_dict({k[len("encoder.resnet."):]: v for k, v in tp.items()}, strict=False)
+    trunk = trunk.to(dev).train()
+    feat = trunk(images.to(dev), 1)
+    torch.cuda.synchronize()
+    err = rel_l2(feat.float(), want)
+    print(f"bf16 resnet50 trunk rel-L2 error vs fp32 oracle: {err:.3e}")
+    assert err < 8e-2      # 53 stacked BatchNorms over only N*2*2 = 16 samples in the last stage amplify bf16 rounding
+
+
+def test_encoder_head_matches_reference_composition(dev):
+    """Linear + BatchNorm1d(momentum=0.01) forward/backward vs the golden vectors (reference's own nn modules)."""
+    from gan_image_captioning_amd import encoder_engine
+    g = Golden("tiny_cgan_head")
+    gp = g.group("gp0/")
+    tf = g.t("trunk_feat")
+    leaf = {k: gp[k].clone().requires_grad_(True) for k in ("encoder.linear.weight", "encoder.linear.bias", "encoder.bn.weight", "encoder.bn.bias")}
+    run = {"running_mean": torch.zeros(g.meta["E"]), "running_var": torch.ones(g.meta["E"])}
+    want = O.encoder_head(leaf, tf, training=True, running=run)
+    rg = torch.Generator().manual_seed(1)
+    d_out = torch.randn(want.shape, generator=rg)
+    (want * d_out).sum().backward()
+    rm, rv = torch.zeros(g.meta["E"], device=dev), torch.ones(g.meta["E"], device=dev)
+    out, saved = encoder_engine.head_fwd(0, tf.to(dev), gp["encoder.linear.weight"].to(dev), gp["encoder.linear.bias"].to(dev),
+                                         gp["encoder.bn.weight"].to(dev), gp["encoder.bn.bias"].to(dev), rm, rv, True, 0.01, 1e-5)
+    dw, db, dg, dbt = encoder_engine.head_bwd(0, saved, gp["encoder.linear.weight"].to(dev), gp["encoder.bn.weight"].to(dev), d_out.to(dev))
+    torch.cuda.synchronize()
+    close(out, want, rtol=1e-4, atol_scale=1e-5, what="head out")
+    close(rm, run["running_mean"], rtol=1e-4, atol_scale=1e-6, what="running_mean")
+    close(rv, run["running_var"], rtol=1e-4, atol_scale=1e-6, what="running_var")
+    close(dw, leaf["encoder.linear.weight"].grad, rtol=2e-3, atol_scale=1e-4, what="d linear.weight")
+    close(db, leaf["encoder.linear.bias"].grad, rtol=2e-3, atol_scale=1e-4, what="d linear.bias", atol_abs=1e-6)
+    close(dg, leaf["encoder.bn.weight"].grad, rtol=2e-3, atol_scale=1e-4, what="d bn.weight")
+    close(dbt, leaf["encoder.bn.bias"].grad, rtol=2e-3, atol_scale=1e-4, what="d bn.bias")
+
+
+@pytest.mark.parametrize("impl", ["fused", "autograd"])
+def test_conditional_step_f32_matches_oracle(dev, impl):
+    """--conditional-gan 1, ResNet-18 @64x64, batch 8 (SURVEY cfg1): the whole step against the CPU oracle."""
+    from tests.test_gpu_step import make_instructor
+    from tests.gpu_util import dec_param_names, disc_param_names
+    m = dict(B=8, L=10, V=64, E=32, H=512, NL=1, De=64, R=64, fs=[3, 4, 5], nf=[300, 300, 300], loss="standard", clip=5.0,
+             gen_lr=1e-4, disc_lr=1e-4, T0=100, adapt="exp", adv_epochs=30)
+    g = torch.Generator().manual_seed(2024)
+    gp = O.make_gen_params(m["V"], m["E"], m["H"], m["NL"], g, trunk_feat_dim=512)
+    dp = O.make_disc_params(m["V"], g)
+    tp = OE.make_trunk_params("resnet18", g)
+    caps = O.make_captions(m["B"], m["L"], m["V"], g)
+    images = torch.randn(m["B"], 3, 64, 64, generator=g)
+    us, masks = O.make_noise(m["B"], m["L"], m["V"], 900, 64, g)
+    T = 1.2
+    feat = OE.trunk_forward(tp, images, "resnet18")
+    ref = O.adv_step(dict(gp), dict(dp), caps, us, masks, T, "standard", 5.0, None, None, trunk_feat=feat)
+    from gan_image_captioning_amd.args import default_args
+    from gan_image_captioning_amd.training import GANInstructor
+    args = default_args(vocab_size=m["V"], gen_embed_dim=m["E"], gen_hidden_dim=m["H"], conditional_gan=1, encoder_arch="resnet18",
+                        compute_dtype="fp32", step_impl=impl, device="cuda", log_file=None, model_dir=None, save_dir=None, image_size=64)
+    inst = GANInstructor(args, None, None)
+    with torch.no_grad():
+        for n, p in zip(dec_param_names(1), inst.gen.decoder.param_list()):
+            p.copy_(gp[n])
+        for n, p in zip(disc_param_names(3), inst.disc.param_list()):
+            p.copy_(dp[n])
+        inst.gen.encoder.resnet.load_state_dict({k[len("encoder.resnet."):]: v for k, v in tp.items()}, strict=False)
+        for n in ("linear.weight", "linear.bias", "bn.weight", "bn.bias"):
+            mod, attr = n.split(".")
+            getattr(getattr(inst.gen.encoder, mod), attr).copy_(gp["encoder." + n])
+    inst.gen.train(); inst.disc.train()
+    inst.gen.decoder.temperature = T
+    u = torch.stack(us).to(dev)
+    km = [k.to(dev) for k in masks]
+    if impl == "fused":
+        out = inst.fused(images.to(dev), caps.to(dev), m["L"], True, u, km, opt_step=False)
+        losses = out["losses"]
+        torch.cuda.synchronize()
+        assert torch.equal(out["ids"].cpu(), ref["ids"])
+    else:
+        from gan_image_captioning_amd.utils import get_losses
+        feats = inst._features(images.to(dev), m["B"])
+        gen_caps, ids = inst.gen.decoder.sample(feats, max_caption_len=m["L"], noise_u=u)
+        d_real = inst.disc(caps.to(dev), keep_mask=km[0])
+        d_fake = inst.disc(gen_caps.detach(), keep_mask=km[1])
+        with inst.disc.input_grad_only():
+            g_out = inst.disc(gen_caps, keep_mask=km[2])
+        g_loss, d_loss = get_losses(d_real, d_fake, g_out, "standard", detach_d_for_g=True)
+        inst.disc_opt.zero_grad(); inst.gen_opt.zero_grad()
+        d_loss.backward(); g_loss.backward()
+        losses = torch.stack([g_loss.detach(), d_loss.detach()])
+        torch.cuda.synchronize()
+        assert torch.equal(ids.cpu(), ref["ids"])
+    assert float(losses[0]) == pytest.approx(ref["g_loss"], rel=1e-4)
+    assert float(losses[1]) == pytest.approx(ref["d_loss"], rel=1e-4)
+    want = {**ref["g_grads_raw"], **ref["d_grads_raw"]}
+    enc = inst.gen.encoder
+    got = {"encoder.linear.weight": enc.linear.weight.grad, "encoder.linear.bias": enc.linear.bias.grad,
+           "encoder.bn.weight": enc.bn.weight.grad, "encoder.bn.bias": enc.bn.bias.grad}
+    got.update({n: p.grad for n, p in zip(dec_param_names(1), inst.gen.decoder.param_list())})
+    for n in ("encoder.linear.weight", "encoder.bn.weight", "encoder.bn.bias", "decoder.lstm.weight_ih_l0", "decoder.linear.weight"):
+        err = rel_l2(got[n], want[n])
+        assert err < 2e-2, f"{n}: rel L2 {err}"
