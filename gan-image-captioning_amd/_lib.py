@@ -82,7 +82,7 @@ class DiscBwdWs(C.Structure):
 
 class BnRunningDesc(C.Structure):
     _fields_ = [("stats", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p), ("count", C.c_float),
-                ("momentum", C.c_float), ("C", C.c_int32), ("pad_", C.c_int32)]
+                ("momentum", C.c_float), ("C", C.c_int32), ("nrep", C.c_int32)]
 
 
 _P = C.POINTER
@@ -107,9 +107,9 @@ _SIGNATURES = {
                                C.c_int64, c_void_p, C.c_int, c_void_p, _P(DiscGrads), C.c_int, c_void_p, C.c_int64, c_void_p]),
     "gic_pack_image": (C.c_int, [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),
     "gic_repack_conv_weight": (C.c_int, [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),
-    "gic_conv2d": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int] + [C.c_int] * 9 + [c_void_p]),
-    "gic_bn_act": (C.c_int, [c_void_p] * 12 + [C.c_float, C.c_int, c_void_p, C.c_int, C.c_int64, C.c_int, c_void_p]),
-    "gic_bn_relu_maxpool": (C.c_int, [c_void_p] * 6 + [C.c_float, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),
+    "gic_conv2d": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int] + [C.c_int] * 9 + [c_void_p]),
+    "gic_bn_act": (C.c_int, [c_void_p] * 12 + [C.c_int, C.c_float, C.c_int, c_void_p, C.c_int, C.c_int64, C.c_int, c_void_p]),
+    "gic_bn_relu_maxpool": (C.c_int, [c_void_p] * 6 + [C.c_int, C.c_float, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),
     "gic_avgpool": (C.c_int, [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),
     "gic_bn_running_update": (C.c_int, [c_void_p, C.c_int, c_void_p]),
     "gic_bn1d_fwd": (C.c_int, [c_void_p] * 5 + [C.c_int, C.c_float, C.c_float, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, c_void_p]),

@@ -57,7 +57,8 @@ __global__ void repack_conv_weight_kernel(const float* __restrict__ w, TA* __res
 }
 
 struct BnSrc {            // y-side or residual-side BatchNorm inputs; stats == nullptr -> identity (no BN)
-  const float* stats;     // [2C]: sum, sum of squares
+  const float* stats;     // [nrep][2C]: sum, sum of squares (replicas are summed here)
+  int nrep;
   const float* gamma;
   const float* beta;
   const float* run_mean;  // eval mode (stats == nullptr but run_mean != nullptr)
@@ -67,8 +68,10 @@ struct BnSrc {            // y-side or residual-side BatchNorm inputs; stats == 
 __device__ __forceinline__ void bn_coeffs(const BnSrc& b, int c, int C, float inv_count, float& scale, float& shift) {
   float mean, var;
   if (b.stats) {
-    mean = b.stats[c] * inv_count;
-    var = fmaxf(b.stats[C + c] * inv_count - mean * mean, 0.f);
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < b.nrep; ++r) { s1 += b.stats[(long)r * 2 * C + c]; s2 += b.stats[(long)r * 2 * C + C + c]; }
+    mean = s1 * inv_count;
+    var = fmaxf(s2 * inv_count - mean * mean, 0.f);
   } else if (b.run_mean) {
     mean = b.run_mean[c]; var = b.run_var[c];
   } else { scale = 1.f; shift = 0.f; return; }
@@ -76,69 +79,82 @@ __device__ __forceinline__ void bn_coeffs(const BnSrc& b, int c, int C, float in
   shift = b.beta[c] - mean * scale;
 }
 
-// ---- out = [relu]( bn(y) + (res ? bn_res(res) : 0) ), rows x C, 4 channels per thread.
-// The launch makes gridDim.x*256 a multiple of C/4, so a thread keeps ONE channel quad for all its rows and
-// derives its BatchNorm scale/shift (from the raw sums) once.
-template <typename TA>
-__global__ void bn_act_kernel(const TA* __restrict__ y, BnSrc by, const TA* __restrict__ res, BnSrc br, float inv_count, int relu,
-                              TA* __restrict__ out, long rows, int C) {
-  const int cq = C >> 2;
-  const long total = rows * cq;
-  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c0 = (int)(i0 % cq) * 4;
-  float sc[4], sh[4], rs[4] = {1.f, 1.f, 1.f, 1.f}, rh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    bn_coeffs(by, c0 + k, C, inv_count, sc[k], sh[k]);
-    if (res) bn_coeffs(br, c0 + k, C, inv_count, rs[k], rh[k]);
+// Block-cooperative BatchNorm coefficients: the 256 threads fold the statistics replicas of all C channels once
+// into LDS ([scale | shift] (+ the residual's pair)); afterwards every element costs one LDS read per coefficient.
+__device__ __forceinline__ void stage_coeffs(float* coef, const BnSrc& b, int C, float inv_count) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float sc, sh;
+    bn_coeffs(b, c, C, inv_count, sc, sh);
+    coef[c] = sc;
+    coef[C + c] = sh;
   }
-  for (long i = i0; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long o = (i / cq) * C + c0;
-    float v[4];
-    TA yv[4], rv[4];
-    if constexpr (sizeof(TA) == 4) *(float4*)yv = *(const float4*)(y + o); else *(uint2*)yv = *(const uint2*)(y + o);
-    if (res) { if constexpr (sizeof(TA) == 4) *(float4*)rv = *(const float4*)(res + o); else *(uint2*)rv = *(const uint2*)(res + o); }
+}
+
+template <typename TA> struct Vec16 { static constexpr int N = 16 / sizeof(TA); };
+
+// ---- out = [relu]( bn(y) + (res ? bn_res(res) : 0) ), rows x C; 16 bytes (8 bf16 / 4 f32 channels) per access
+template <typename TA>
+__global__ __launch_bounds__(256) void bn_act_kernel(const TA* __restrict__ y, BnSrc by, const TA* __restrict__ res, BnSrc br,
+                                                      float inv_count, int relu, TA* __restrict__ out, long rows, int C) {
+  extern __shared__ __attribute__((aligned(16))) float coef[];      // [4][C]
+  constexpr int VN = Vec16<TA>::N;
+  stage_coeffs(coef, by, C, inv_count);
+  if (res) stage_coeffs(coef + 2 * C, br, C, inv_count);
+  __syncthreads();
+  const int cv = C / VN;
+  const long total = rows * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cv) * VN;
+    const long o = (i / cv) * C + c0;
+    TA yv[VN], rv[VN], ov[VN];
+    *(uint4*)yv = *(const uint4*)(y + o);
+    if (res) *(uint4*)rv = *(const uint4*)(res + o);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      v[k] = to_f32<TA>(yv[k]) * sc[k] + sh[k];
-      if (res) v[k] += to_f32<TA>(rv[k]) * rs[k] + rh[k];
-      if (relu) v[k] = fmaxf(v[k], 0.f);
+    for (int k = 0; k < VN; ++k) {
+      float v = to_f32<TA>(yv[k]) * coef[c0 + k] + coef[C + c0 + k];
+      if (res) v += to_f32<TA>(rv[k]) * coef[2 * C + c0 + k] + coef[3 * C + c0 + k];
+      if (relu) v = fmaxf(v, 0.f);
+      ov[k] = from_f32<TA>(v);
     }
-    TA o4[4] = {from_f32<TA>(v[0]), from_f32<TA>(v[1]), from_f32<TA>(v[2]), from_f32<TA>(v[3])};
-    if constexpr (sizeof(TA) == 4) *(float4*)(out + o) = *(const float4*)o4;
-    else *(uint2*)(out + o) = *(const uint2*)o4;
+    *(uint4*)(out + o) = *(const uint4*)ov;
   }
 }
 
 // ---- stem: relu(bn(y)) then 3x3 stride-2 pad-1 max-pool.  y [N,H,W,C] -> out [N,Ho,Wo,C]
 template <typename TA>
-__global__ void bn_relu_maxpool_kernel(const TA* __restrict__ y, BnSrc by, float inv_count, TA* __restrict__ out, int N, int H, int W,
-                                       int C, int Ho, int Wo) {
-  const int cq = C >> 2;
-  const long total = (long)N * Ho * Wo * cq;
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const TA* __restrict__ y, BnSrc by, float inv_count, TA* __restrict__ out,
+                                                               int N, int H, int W, int C, int Ho, int Wo) {
+  extern __shared__ __attribute__((aligned(16))) float coef[];      // [2][C]
+  constexpr int VN = Vec16<TA>::N;
+  stage_coeffs(coef, by, C, inv_count);
+  __syncthreads();
+  const int cv = C / VN;
+  const long total = (long)N * Ho * Wo * cv;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cq) * 4;
-    long t = i / cq;
+    const int c0 = (int)(i % cv) * VN;
+    long t = i / cv;
     const int wo = (int)(t % Wo); t /= Wo;
     const int ho = (int)(t % Ho);
     const int n = (int)(t / Ho);
-    float sc[4], sh[4], best[4];
+    float best[VN];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { bn_coeffs(by, c0 + k, C, inv_count, sc[k], sh[k]); best[k] = -INFINITY; }
+    for (int k = 0; k < VN; ++k) best[k] = 0.f;          // relu output is >= 0 and every window holds >= 1 pixel
     for (int r = 0; r < 3; ++r) {
       const int h = ho * 2 - 1 + r;
       if (h < 0 || h >= H) continue;
       for (int s = 0; s < 3; ++s) {
         const int w = wo * 2 - 1 + s;
         if (w < 0 || w >= W) continue;
-        const TA* p = y + (((long)n * H + h) * W + w) * C + c0;
+        TA pv[VN];
+        *(uint4*)pv = *(const uint4*)(y + (((long)n * H + h) * W + w) * C + c0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) best[k] = fmaxf(best[k], fmaxf(to_f32<TA>(p[k]) * sc[k] + sh[k], 0.f));
+        for (int k = 0; k < VN; ++k) best[k] = fmaxf(best[k], to_f32<TA>(pv[k]) * coef[c0 + k] + coef[C + c0 + k]);
       }
     }
-    TA* o = out + (((long)n * Ho + ho) * Wo + wo) * C + c0;
+    TA ov[VN];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = from_f32<TA>(best[k]);
+    for (int k = 0; k < VN; ++k) ov[k] = from_f32<TA>(best[k]);
+    *(uint4*)(out + (((long)n * Ho + ho) * Wo + wo) * C + c0) = *(const uint4*)ov;
   }
 }
 
@@ -163,8 +179,10 @@ __global__ void bn_running_update_kernel(const gic_bn_running_desc* __restrict__
   const float inv = 1.f / d.count;
   const float unbias = d.count > 1.f ? d.count / (d.count - 1.f) : 1.f;
   for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
-    const float mean = d.stats[c] * inv;
-    const float var = fmaxf(d.stats[d.C + c] * inv - mean * mean, 0.f);
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < d.nrep; ++r) { s1 += d.stats[(long)r * 2 * d.C + c]; s2 += d.stats[(long)r * 2 * d.C + d.C + c]; }
+    const float mean = s1 * inv;
+    const float var = fmaxf(s2 * inv - mean * mean, 0.f);
     d.running_mean[c] = (1.f - d.momentum) * d.running_mean[c] + d.momentum * mean;
     d.running_var[c] = (1.f - d.momentum) * d.running_var[c] + d.momentum * var * unbias;
   }
@@ -231,9 +249,9 @@ inline int grid_periodic(long total, int period, int cap = 4096) {
   return g;
 }
 
-BnSrc make_src(const float* stats, const float* gamma, const float* beta, const float* rm, const float* rv) {
+BnSrc make_src(const float* stats, int nrep, const float* gamma, const float* beta, const float* rm, const float* rv) {
   BnSrc s;
-  s.stats = stats; s.gamma = gamma; s.beta = beta; s.run_mean = rm; s.run_var = rv;
+  s.stats = stats; s.nrep = nrep < 1 ? 1 : nrep; s.gamma = gamma; s.beta = beta; s.run_mean = rm; s.run_var = rv;
   return s;
 }
 
@@ -267,8 +285,8 @@ int gic_repack_conv_weight(const float* w, void* out, int dtype, int Cout, int C
   return GIC_OK;
 }
 
-int gic_conv2d(const void* in, const void* w, void* out, float* stats, int dtype, int N, int H, int W, int Cin, int Cout, int KH,
-               int KW, int stride, int pad, void* stream) {
+int gic_conv2d(const void* in, const void* w, void* out, float* stats, int stats_nrep, int dtype, int N, int H, int W, int Cin, int Cout,
+               int KH, int KW, int stride, int pad, void* stream) {
   GIC_CHECK_ARG(in && w && out, "conv2d: null pointer");
   GIC_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "conv2d: bad dims");
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
@@ -281,35 +299,42 @@ int gic_conv2d(const void* in, const void* w, void* out, float* stats, int dtype
   g.conv = 1; g.cH = H; g.cW = W; g.cCin = Cin; g.cHo = Ho; g.cWo = Wo; g.cKH = KH; g.cKW = KW; g.cStride = stride; g.cPad = pad;
   g.epi = stats ? EPI_BNSTATS : EPI_PLAIN;
   g.stats = stats;
+  g.stats_nrep = stats_nrep < 1 ? 1 : stats_nrep;
   return gemm(g, (hipStream_t)stream);
 }
 
 int gic_bn_act(const void* y, const float* stats, const float* gamma, const float* beta, const float* run_mean, const float* run_var,
                const void* res, const float* res_stats, const float* res_gamma, const float* res_beta, const float* res_run_mean,
-               const float* res_run_var, float count, int relu, void* out, int dtype, int64_t rows, int C, void* stream) {
-  GIC_CHECK_ARG(y && out && gamma && beta && (stats || run_mean) && C % 4 == 0 && rows > 0 && count > 0, "bn_act: bad argument");
-  const BnSrc by = make_src(stats, gamma, beta, run_mean, run_var);
-  const BnSrc br = make_src(res_stats, res_gamma, res_beta, res_run_mean, res_run_var);
-  const long total = rows * (C / 4);
-  GIC_CHECK_ARG(((C / 4) & (C / 4 - 1)) == 0, "bn_act: C/4 must be a power of two (got C=%d)", C);
-  if (dtype == DT_F32)
-    hipLaunchKernelGGL((bn_act_kernel<float>), dim3(grid_periodic(total, C / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)y, by, (const float*)res, br, 1.f / count, relu, (float*)out, (long)rows, C);
-  else
-    hipLaunchKernelGGL((bn_act_kernel<bf16_t>), dim3(grid_periodic(total, C / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, by, (const bf16_t*)res, br, 1.f / count, relu, (bf16_t*)out, (long)rows, C);
+               const float* res_run_var, int stats_nrep, float count, int relu, void* out, int dtype, int64_t rows, int C, void* stream) {
+  GIC_CHECK_ARG(y && out && gamma && beta && (stats || run_mean) && rows > 0 && count > 0, "bn_act: bad argument");
+  const BnSrc by = make_src(stats, stats_nrep, gamma, beta, run_mean, run_var);
+  const BnSrc br = make_src(res_stats, stats_nrep, res_gamma, res_beta, res_run_mean, res_run_var);
+  GIC_CHECK_ARG(C % 8 == 0, "bn_act: C must be a multiple of 8 (got %d)", C);
+  const size_t lds = (size_t)4 * C * sizeof(float);
+  if (dtype == DT_F32) {
+    const long total = rows * (C / 4);
+    hipLaunchKernelGGL((bn_act_kernel<float>), dim3(grid1d(total, 1024)), dim3(256), lds, (hipStream_t)stream, (const float*)y, by, (const float*)res, br, 1.f / count, relu, (float*)out, (long)rows, C);
+  } else {
+    const long total = rows * (C / 8);
+    hipLaunchKernelGGL((bn_act_kernel<bf16_t>), dim3(grid1d(total, 1024)), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)y, by, (const bf16_t*)res, br, 1.f / count, relu, (bf16_t*)out, (long)rows, C);
+  }
   GIC_CHECK_LAUNCH("bn_act");
   return GIC_OK;
 }
 
 int gic_bn_relu_maxpool(const void* y, const float* stats, const float* gamma, const float* beta, const float* run_mean,
-                        const float* run_var, float count, void* out, int dtype, int N, int H, int W, int C, void* stream) {
-  GIC_CHECK_ARG(y && out && gamma && beta && (stats || run_mean) && C % 4 == 0, "bn_relu_maxpool: bad argument");
+                        const float* run_var, int stats_nrep, float count, void* out, int dtype, int N, int H, int W, int C, void* stream) {
+  GIC_CHECK_ARG(y && out && gamma && beta && (stats || run_mean) && C % 8 == 0, "bn_relu_maxpool: bad argument");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const BnSrc by = make_src(stats, gamma, beta, run_mean, run_var);
-  const long total = (long)N * Ho * Wo * (C / 4);
-  if (dtype == DT_F32)
-    hipLaunchKernelGGL((bn_relu_maxpool_kernel<float>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, (const float*)y, by, 1.f / count, (float*)out, N, H, W, C, Ho, Wo);
-  else
-    hipLaunchKernelGGL((bn_relu_maxpool_kernel<bf16_t>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, by, 1.f / count, (bf16_t*)out, N, H, W, C, Ho, Wo);
+  const BnSrc by = make_src(stats, stats_nrep, gamma, beta, run_mean, run_var);
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  if (dtype == DT_F32) {
+    const long total = (long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL((bn_relu_maxpool_kernel<float>), dim3(grid1d(total, 1024)), dim3(256), lds, (hipStream_t)stream, (const float*)y, by, 1.f / count, (float*)out, N, H, W, C, Ho, Wo);
+  } else {
+    const long total = (long)N * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL((bn_relu_maxpool_kernel<bf16_t>), dim3(grid1d(total, 1024)), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)y, by, 1.f / count, (bf16_t*)out, N, H, W, C, Ho, Wo);
+  }
   GIC_CHECK_LAUNCH("bn_relu_maxpool");
   return GIC_OK;
 }

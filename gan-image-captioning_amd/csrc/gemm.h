@@ -40,7 +40,8 @@ struct GemmDesc {
   int conv = 0;
   int cH = 0, cW = 0, cCin = 0, cHo = 0, cWo = 0, cKH = 0, cKW = 0, cStride = 1, cPad = 0;
   // ---- EPI_BNSTATS: C = result (+bias) and stats[n] += sum_m v, stats[N+n] += sum_m v^2 (f32 atomics)
-  float* stats = nullptr;
+  float* stats = nullptr;   // [stats_nrep][2N]; block b adds into replica b % stats_nrep (readers sum the replicas)
+  int stats_nrep = 1;
 };
 
 // Enqueue on `stream`. Returns GIC_OK or a negative Status (message via gic_last_error()).

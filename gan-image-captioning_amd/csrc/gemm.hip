@@ -45,7 +45,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
   constexpr bool IS_BF16 = (SZ == 2);
   typedef typename GlobalPtr<TI>::type gptr_t;
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
+  constexpr int EPI_BYTES = BM * (BN * (int)sizeof(TO) + 16) + 4 * (BN / 2) * 2 * 4;   // staged C tile + stats scratch
+  constexpr int SMEM_BYTES = 2 * BUF_BYTES > EPI_BYTES ? 2 * BUF_BYTES : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wr = w >> 1, wc = w & 1;
@@ -301,6 +303,66 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
   // ---- epilogue.  C/D map: col = lane&15, row = (lane>>4)*4 + reg
   TO* __restrict__ C = (TO*)d.C;
   const bool split = gridDim.y > 1;
+
+  // Staged path (conv / plain products that overwrite C): the tile goes through LDS so that every global store
+  // is a 16-byte piece of a contiguous output row (a direct store of the MFMA layout writes 32-byte row
+  // fragments, 2 bytes per lane), and the BatchNorm column sums are folded across the block before ONE atomic
+  // per column lands in one of `stats_nrep` replicas (few adders per address: global f32 atomics serialise).
+  if constexpr (EPI != EPI_HIGHWAY) {
+    constexpr int OSZ = sizeof(TO);
+    constexpr int OVE = 16 / OSZ;
+    constexpr int SC = BN * OSZ + 16;                       // LDS row stride of the C tile
+    static_assert(BM * SC + 4 * (BN / 2) * 2 * 4 <= SMEM_BYTES, "C tile + stats scratch must fit the LDS allocation");
+    const bool staged = !split && !d.accumulate && (N % OVE == 0) && (d.ldc % OVE == 0) && ((((uintptr_t)d.C) & 15) == 0);
+    if (staged) {
+      unsigned char* sC = smem;
+      float* sStat = (float*)(smem + BM * SC);               // [4 waves][BN/2][2]
+      float st_s[TN], st_q[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nl = wc * (BN / 2) + j * 16 + lr;
+        const int n = bn0 + nl;
+        const float bias = (d.bias && n < N) ? d.bias[n] : 0.f;
+        st_s[j] = 0.f; st_q[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ml = wr * (BM / 2) + i * 16 + lg * 4 + r;
+            const float v = d.alpha * acc[i][j][r] + bias;
+            *(TO*)(sC + ml * SC + nl * OSZ) = from_f32<TO>(v);
+            if (EPI == EPI_BNSTATS && bm0 + ml < M) { st_s[j] += v; st_q[j] += v * v; }
+          }
+        }
+        if constexpr (EPI == EPI_BNSTATS) {
+          st_s[j] += __shfl_xor(st_s[j], 16, 64); st_q[j] += __shfl_xor(st_q[j], 16, 64);
+          st_s[j] += __shfl_xor(st_s[j], 32, 64); st_q[j] += __shfl_xor(st_q[j], 32, 64);
+          if (lg == 0) { sStat[(w * (BN / 2) + j * 16 + lr) * 2] = st_s[j]; sStat[(w * (BN / 2) + j * 16 + lr) * 2 + 1] = st_q[j]; }
+        }
+      }
+      __syncthreads();
+      if constexpr (EPI == EPI_BNSTATS) {
+        if (tid < BN) {                                        // column tid: waves (wr=0, wc) and (wr=1, wc)
+          const int cwc = tid / (BN / 2), cl = tid % (BN / 2), n = bn0 + tid;
+          if (n < N) {
+            const float s0 = sStat[((0 * 2 + cwc) * (BN / 2) + cl) * 2] + sStat[((1 * 2 + cwc) * (BN / 2) + cl) * 2];
+            const float q0 = sStat[((0 * 2 + cwc) * (BN / 2) + cl) * 2 + 1] + sStat[((1 * 2 + cwc) * (BN / 2) + cl) * 2 + 1];
+            float* st = d.stats + (long)(blockIdx.x % d.stats_nrep) * 2 * N;
+            atomicAdd(&st[n], s0);
+            atomicAdd(&st[N + n], q0);
+          }
+        }
+      }
+      constexpr int CPR = BN / OVE;                            // 16-B chunks per tile row
+      for (int c = tid; c < BM * CPR; c += 256) {
+        const int ml = c / CPR, cc = c % CPR;
+        const int m = bm0 + ml, n = bn0 + cc * OVE;
+        if (m < M && n < N) *(u32x4*)(C + (long)m * d.ldc + n) = *(const u32x4*)(sC + ml * SC + cc * 16);
+      }
+      return;
+    }
+  }
+
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -351,7 +413,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
         // column n lives in lanes {lr, lr+16, lr+32, lr+48}: fold the 4 row groups, one atomic pair per column
         st_s += __shfl_xor(st_s, 16, 64); st_q += __shfl_xor(st_q, 16, 64);
         st_s += __shfl_xor(st_s, 32, 64); st_q += __shfl_xor(st_q, 32, 64);
-        if (lg == 0) { atomicAdd(&d.stats[n], st_s); atomicAdd(&d.stats[N + n], st_q); }
+        float* st = d.stats + (long)(blockIdx.x % d.stats_nrep) * 2 * N;
+        if (lg == 0) { atomicAdd(&st[n], st_s); atomicAdd(&st[N + n], st_q); }
       }
     }
   }

@@ -19,6 +19,7 @@ from . import engine
 from .engine import ptr, stream_ptr
 
 AVAILABLE = True
+STATS_REPLICAS = 16      # BatchNorm sum replicas: conv workgroup b adds into replica b % 16 (global f32 atomics serialise per address)
 
 
 def _check(status, what):
@@ -54,7 +55,7 @@ class TrunkPlan:
         off = 0
         for s in self.steps:
             s.stats_off = off
-            off += 2 * s.cout
+            off += 2 * s.cout * STATS_REPLICAS
         self.stats_len = off
         self._wkey = None
         self._bufs: Dict[Tuple[int, int], dict] = {}
@@ -136,6 +137,7 @@ class TrunkPlan:
             table[i].count = float(rows[s.name])
             table[i].momentum = float(s.bn.momentum)
             table[i].C = s.cout
+            table[i].nrep = STATS_REPLICAS
         raw = bytes(table)
         b["table"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self._bufs[key] = b
@@ -144,7 +146,7 @@ class TrunkPlan:
     # ---------------------------------------------------------------- kernels
     def _conv(self, s: _ConvStep, x: torch.Tensor, y: torch.Tensor, stats: Optional[torch.Tensor], N, H, W, cin=None, kw=None, pad=None):
         st = None if stats is None else stats.data_ptr() + 4 * s.stats_off
-        _check(L.load().gic_conv2d(ptr(x), ptr(s.w), ptr(y), st, self.dtype, N, H, W, cin if cin is not None else s.cin, s.cout, s.k,
+        _check(L.load().gic_conv2d(ptr(x), ptr(s.w), ptr(y), st, STATS_REPLICAS, self.dtype, N, H, W, cin if cin is not None else s.cin, s.cout, s.k,
                                    kw if kw is not None else s.k, s.stride, pad if pad is not None else s.pad, stream_ptr()), "gic_conv2d " + s.name)
 
     def _bn_args(self, s: Optional[_ConvStep], stats: Optional[torch.Tensor], training: bool):
@@ -159,7 +161,7 @@ class TrunkPlan:
     def _bn_act(self, s, y, out, stats, training, rows, relu=True, res=None, res_step=None):
         a = self._bn_args(s, stats, training)
         r = self._bn_args(res_step, stats, training)
-        _check(L.load().gic_bn_act(ptr(y), *a, ptr(res), *r, float(rows), int(relu), ptr(out), self.dtype, rows, s.cout, stream_ptr()),
+        _check(L.load().gic_bn_act(ptr(y), *a, ptr(res), *r, STATS_REPLICAS, float(rows), int(relu), ptr(out), self.dtype, rows, s.cout, stream_ptr()),
                "gic_bn_act " + s.name)
 
     def forward(self, images: torch.Tensor, training: bool) -> torch.Tensor:
@@ -183,7 +185,7 @@ class TrunkPlan:
         self._conv(self.stem, b["xin"], b["y0"], stats, N, S + 6, S + 6, cin=4, kw=8, pad=0)
         h = b["y0"].shape[1]
         a = self._bn_args(self.stem, stats, training)
-        _check(lib.gic_bn_relu_maxpool(ptr(b["y0"]), *a, float(rows[self.stem.name]), ptr(b["x0"]), self.dtype, N, h, h, 64, stream_ptr()),
+        _check(lib.gic_bn_relu_maxpool(ptr(b["y0"]), *a, STATS_REPLICAS, float(rows[self.stem.name]), ptr(b["x0"]), self.dtype, N, h, h, 64, stream_ptr()),
                "gic_bn_relu_maxpool")
         x = b["x0"]
         for blk, e in zip(self.blocks, b["blocks"]):

@@ -216,30 +216,32 @@ int gic_pack_image(const float* nchw, void* out, int dtype, int N, int S, int pa
 int gic_repack_conv_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cin_pad, int KW_pad,
                            void* stream);
 /* Implicit-GEMM convolution on MFMA: in act [N,H,W,Cin], w act [Cout,KH,KW,Cin], out act [N,Ho,Wo,Cout].  stats (optional,
- * f32 [2*Cout], accumulated with atomics: the caller zeroes it): per-channel sum and sum of squares of the f32 results =
- * the batch statistics nn.BatchNorm2d needs in train mode.  Replaces nn.Conv2d of the torchvision trunk (generator.py:12-14,22). */
-int gic_conv2d(const void* in, const void* w, void* out, float* stats, int dtype, int N, int H, int W, int Cin, int Cout,
-               int KH, int KW, int stride, int pad, void* stream);
+ * f32 [stats_nrep][2*Cout], accumulated with atomics: the caller zeroes it; workgroup b adds into replica b % stats_nrep so that
+ * few adders share an address, readers sum the replicas): per-channel sum and sum of squares of the f32 results = the batch
+ * statistics nn.BatchNorm2d needs in train mode.  Replaces nn.Conv2d of the torchvision trunk (generator.py:12-14,22). */
+int gic_conv2d(const void* in, const void* w, void* out, float* stats, int stats_nrep, int dtype, int N, int H, int W, int Cin,
+               int Cout, int KH, int KW, int stride, int pad, void* stream);
 /* out = [relu]( bn(y) + (res ? bn_res(res) : 0) ) over rows x C.  A BatchNorm takes its mean/var from `stats` (raw sums over
  * `count` rows; train mode) or from run_mean/run_var (eval mode); res_gamma == NULL -> the residual is added as is. */
 int gic_bn_act(const void* y, const float* stats, const float* gamma, const float* beta, const float* run_mean,
                const float* run_var, const void* res, const float* res_stats, const float* res_gamma, const float* res_beta,
-               const float* res_run_mean, const float* res_run_var, float count, int relu, void* out, int dtype, int64_t rows,
-               int C, void* stream);
+               const float* res_run_mean, const float* res_run_var, int stats_nrep, float count, int relu, void* out, int dtype,
+               int64_t rows, int C, void* stream);
 /* Stem: relu(bn(y)) then 3x3 / stride 2 / pad 1 max-pool.  y act [N,H,W,C] -> out act [N,(H+1)/2,(W+1)/2,C]. */
 int gic_bn_relu_maxpool(const void* y, const float* stats, const float* gamma, const float* beta, const float* run_mean,
-                        const float* run_var, float count, void* out, int dtype, int N, int H, int W, int C, void* stream);
+                        const float* run_var, int stats_nrep, float count, void* out, int dtype, int N, int H, int W, int C,
+                        void* stream);
 /* Global average pool: x act [N,HW,C] -> out act [N,C]. */
 int gic_avgpool(const void* x, void* out, int dtype, int N, int HW, int C, void* stream);
 /* Running mean/var of every trunk BatchNorm2d in one launch; `table_dev` is a DEVICE array built once by the caller. */
 typedef struct gic_bn_running_desc {
-  const float* stats;      /* [2C] raw sums of this step */
+  const float* stats;      /* [nrep][2C] raw sums of this step */
   float* running_mean;     /* [C] */
   float* running_var;      /* [C] */
   float count;             /* rows the sums were taken over */
   float momentum;
   int32_t C;
-  int32_t pad_;
+  int32_t nrep;
 } gic_bn_running_desc;
 int gic_bn_running_update(const gic_bn_running_desc* table_dev, int nlayers, void* stream);
 /* nn.BatchNorm1d over the batch axis of x [B,E] (generator.py:16,24) forward / backward. */

@@ -41,11 +41,11 @@ def conv_hip(x_nchw, w, stride, pad, dtype, dev, want_stats=True):
     L.check(L.load().gic_repack_conv_weight(w.to(dev).contiguous().data_ptr(), wp.data_ptr(), dtype, Co, C, k, k, C, k, engine.stream_ptr()), "repack")
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     y = torch.empty(N, Ho, Wo, Co, device=dev, dtype=act)
-    stats = torch.zeros(2 * Co, device=dev)
-    L.check(L.load().gic_conv2d(xh.data_ptr(), wp.data_ptr(), y.data_ptr(), stats.data_ptr() if want_stats else None, dtype,
+    stats = torch.zeros(4, 2 * Co, device=dev)
+    L.check(L.load().gic_conv2d(xh.data_ptr(), wp.data_ptr(), y.data_ptr(), stats.data_ptr() if want_stats else None, 4, dtype,
                                 N, H, W, C, Co, k, k, stride, pad, engine.stream_ptr()), "conv2d")
     torch.cuda.synchronize()
-    return y.float().cpu().permute(0, 3, 1, 2), stats.cpu()
+    return y.float().cpu().permute(0, 3, 1, 2), stats.sum(0).cpu()
 
 
 CONV_CASES = [  # (N, Cin, H, Cout, k, stride, pad)
