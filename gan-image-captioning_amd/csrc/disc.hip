@@ -58,6 +58,29 @@ __global__ void disc_emb_scatter_kernel(const float* __restrict__ demb_f32, cons
   }
 }
 
+// One filter of width F over a single embedding column (s == 1): sliding register window, one LDS read and F fmas per
+// time step, relu then running max with first-index tie-break (discriminator.py:42,45).
+template <int F>
+__device__ __forceinline__ void conv_max_s1(const float* __restrict__ xs, const float* __restrict__ wp, float bias, int L,
+                                            float& best, int& bt) {
+  float w[F], win[F];
+#pragma unroll
+  for (int j = 0; j < F; ++j) w[j] = wp[j];
+#pragma unroll
+  for (int j = 1; j < F; ++j) win[j] = xs[j - 1];
+  best = -1.f; bt = 0;
+  for (int t = 0; t + F <= L; ++t) {
+#pragma unroll
+    for (int j = 0; j + 1 < F; ++j) win[j] = win[j + 1];
+    win[F - 1] = xs[t + F - 1];
+    float v = bias;
+#pragma unroll
+    for (int j = 0; j < F; ++j) v += w[j] * win[j];
+    v = fmaxf(v, 0.f);
+    if (v > best) { best = v; bt = t; }
+  }
+}
+
 // ---- fused conv + bias + ReLU + max-over-time.  grid = B*R blocks, 256 threads stride over the F filters.
 template <typename TA, int MAXT>
 __global__ __launch_bounds__(256) void disc_conv_pool_fwd_kernel(const float* __restrict__ emb, ConvMeta cm, int L, int De, int R,
@@ -72,18 +95,36 @@ __global__ __launch_bounds__(256) void disc_conv_pool_fwd_kernel(const float* __
     if (col < cm.F) {
       const int k = conv_of(cm, col);
       const int f = cm.fsize[k], ch = col - cm.foff[k], taps = f * s;
-      float w[MAXT];
-#pragma unroll
-      for (int j = 0; j < MAXT; ++j) w[j] = j < taps ? cm.w[k][(long)ch * taps + j] : 0.f;
       const float bias = cm.b[k][ch];
-      best = -1.f;
-      for (int t = 0; t + f <= L; ++t) {
-        float v = bias;
+      const float* wp = cm.w[k] + (long)ch * taps;
+      bool done = false;
+      if (s == 1) {
+        done = true;
+        switch (f) {
+          case 1: conv_max_s1<1>(xs, wp, bias, L, best, bt); break;
+          case 2: conv_max_s1<2>(xs, wp, bias, L, best, bt); break;
+          case 3: conv_max_s1<3>(xs, wp, bias, L, best, bt); break;
+          case 4: conv_max_s1<4>(xs, wp, bias, L, best, bt); break;
+          case 5: conv_max_s1<5>(xs, wp, bias, L, best, bt); break;
+          case 6: conv_max_s1<6>(xs, wp, bias, L, best, bt); break;
+          case 7: conv_max_s1<7>(xs, wp, bias, L, best, bt); break;
+          case 8: conv_max_s1<8>(xs, wp, bias, L, best, bt); break;
+          default: done = false;
+        }
+      }
+      if (!done) {
+        float w[MAXT];
 #pragma unroll
-        for (int j = 0; j < MAXT; ++j)
-          if (j < taps) v += w[j] * xs[t * s + j];      // window (t..t+f-1) x s is contiguous in xs
-        v = fmaxf(v, 0.f);                              // relu then max (discriminator.py:42,45)
-        if (v > best) { best = v; bt = t; }
+        for (int j = 0; j < MAXT; ++j) w[j] = j < taps ? wp[j] : 0.f;
+        best = -1.f;
+        for (int t = 0; t + f <= L; ++t) {
+          float v = bias;
+#pragma unroll
+          for (int j = 0; j < MAXT; ++j)
+            if (j < taps) v += w[j] * xs[t * s + j];      // window (t..t+f-1) x s is contiguous in xs
+          v = fmaxf(v, 0.f);                              // relu then max (discriminator.py:42,45)
+          if (v > best) { best = v; bt = t; }
+        }
       }
     }
     pooled[(long)br * cm.Fp + col] = from_f32<TA>(best);
@@ -143,16 +184,16 @@ __global__ __launch_bounds__(256) void disc_conv_pool_bwd_x_kernel(const float* 
 }
 
 // ---- conv backward, weight side: block = 64 filters x 4 row lanes, rows split over gridDim.y
-template <typename TA>
+template <typename TA, int MAXT>
 __global__ __launch_bounds__(256) void disc_conv_pool_bwd_w_kernel(const float* __restrict__ dpooled, const TA* __restrict__ pooled,
                                                                      const uint8_t* __restrict__ argmax, const float* __restrict__ emb,
                                                                      ConvMeta cm, int L, int De, int R, long rows) {
-  __shared__ float red[4][64][kMaxTaps + 1];
+  __shared__ float red[4][64][MAXT + 1];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, s = cm.s;
   const int col = blockIdx.x * 64 + cx;
-  float acc[kMaxTaps + 1];
+  float acc[MAXT + 1];
 #pragma unroll
-  for (int j = 0; j <= kMaxTaps; ++j) acc[j] = 0.f;
+  for (int j = 0; j <= MAXT; ++j) acc[j] = 0.f;
   int k = 0, taps = 0, ch = 0;
   if (col < cm.F) {
     k = conv_of(cm, col);
@@ -165,18 +206,18 @@ __global__ __launch_bounds__(256) void disc_conv_pool_bwd_w_kernel(const float* 
       const int b = (int)(m / R), r = (int)(m % R), t = argmax[o];
       const float* x = emb + ((long)b * L + t) * De + r * s;     // tap (j, e) at x[j*De + e]
 #pragma unroll
-      for (int j = 0; j < kMaxTaps; ++j)
+      for (int j = 0; j < MAXT; ++j)
         if (j < taps) acc[j] += g * x[(j / s) * De + (j % s)];
-      acc[kMaxTaps] += g;
+      acc[MAXT] += g;
     }
   }
 #pragma unroll
-  for (int j = 0; j <= kMaxTaps; ++j) red[ry][cx][j] = acc[j];
+  for (int j = 0; j <= MAXT; ++j) red[ry][cx][j] = acc[j];
   __syncthreads();
   if (ry == 0 && col < cm.F) {
     for (int j = 0; j < taps; ++j)
       atomicAdd(&cm.dw[k][(long)ch * taps + j], red[0][cx][j] + red[1][cx][j] + red[2][cx][j] + red[3][cx][j]);
-    atomicAdd(&cm.db[k][ch], red[0][cx][kMaxTaps] + red[1][cx][kMaxTaps] + red[2][cx][kMaxTaps] + red[3][cx][kMaxTaps]);
+    atomicAdd(&cm.db[k][ch], red[0][cx][MAXT] + red[1][cx][MAXT] + red[2][cx][MAXT] + red[3][cx][MAXT]);
   }
 }
 
@@ -381,8 +422,14 @@ int disc_bwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
   if (G) {
     int gy = cdiv(MR, 4 * 8);
     gy = gy > 64 ? 64 : gy;
-    hipLaunchKernelGGL((disc_conv_pool_bwd_w_kernel<TA>), dim3(cdiv(c.F, 64), gy), dim3(256), 0, stream, (const float*)ws->dpooled,
-                       (const TA*)st->pooled, (const uint8_t*)st->argmax, (const float*)st->emb, c.cm, c.L, c.De, c.R, MR);
+    int mt = 0;
+    for (int k = 0; k < c.cm.nconv; ++k) mt = c.cm.fsize[k] * c.s > mt ? c.cm.fsize[k] * c.s : mt;
+    if (mt <= 8)
+      hipLaunchKernelGGL((disc_conv_pool_bwd_w_kernel<TA, 8>), dim3(cdiv(c.F, 64), gy), dim3(256), 0, stream, (const float*)ws->dpooled,
+                         (const TA*)st->pooled, (const uint8_t*)st->argmax, (const float*)st->emb, c.cm, c.L, c.De, c.R, MR);
+    else
+      hipLaunchKernelGGL((disc_conv_pool_bwd_w_kernel<TA, kMaxTaps>), dim3(cdiv(c.F, 64), gy), dim3(256), 0, stream, (const float*)ws->dpooled,
+                         (const TA*)st->pooled, (const uint8_t*)st->argmax, (const float*)st->emb, c.cm, c.L, c.De, c.R, MR);
     GIC_CHECK_LAUNCH("disc_conv_pool_bwd_w");
   }
   const int n_out = c.L * c.s;

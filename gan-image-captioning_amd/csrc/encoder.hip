@@ -103,20 +103,43 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const TA* __restrict__ y, B
   __syncthreads();
   const int cv = C / VN;
   const long total = rows * cv;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cv) * VN;
-    const long o = (i / cv) * C + c0;
-    TA yv[VN], rv[VN], ov[VN];
-    *(uint4*)yv = *(const uint4*)(y + o);
-    if (res) *(uint4*)rv = *(const uint4*)(res + o);
+  // gridDim.x*256 is a multiple of cv (both powers of two, launch code), so a thread keeps one channel group for all
+  // its rows: its coefficients move from LDS to registers once and the loop is pure load / fma / store.
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = (int)(i0 % cv) * VN;
+  float sc[VN], sh[VN], rs[VN], rh[VN];
 #pragma unroll
-    for (int k = 0; k < VN; ++k) {
-      float v = to_f32<TA>(yv[k]) * coef[c0 + k] + coef[C + c0 + k];
-      if (res) v += to_f32<TA>(rv[k]) * coef[2 * C + c0 + k] + coef[3 * C + c0 + k];
-      if (relu) v = fmaxf(v, 0.f);
-      ov[k] = from_f32<TA>(v);
+  for (int k = 0; k < VN; ++k) {
+    sc[k] = coef[c0 + k]; sh[k] = coef[C + c0 + k];
+    rs[k] = res ? coef[2 * C + c0 + k] : 0.f; rh[k] = res ? coef[3 * C + c0 + k] : 0.f;
+  }
+  // 4 independent 16-byte loads in flight per thread (rows i, i+S, i+2S, i+3S) before any arithmetic
+  const long S = (long)gridDim.x * blockDim.x;
+  for (long i = i0; i < total; i += 4 * S) {
+    TA yv[4][VN], rv[4][VN];
+    long o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long iu = i + u * S;
+      o[u] = (iu / cv) * C + c0;
+      if (iu < total) {
+        *(uint4*)yv[u] = *(const uint4*)(y + o[u]);
+        if (res) *(uint4*)rv[u] = *(const uint4*)(res + o[u]);
+      }
     }
-    *(uint4*)(out + o) = *(const uint4*)ov;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i + u * S >= total) break;
+      TA ov[VN];
+#pragma unroll
+      for (int k = 0; k < VN; ++k) {
+        float v = to_f32<TA>(yv[u][k]) * sc[k] + sh[k];
+        if (res) v += to_f32<TA>(rv[u][k]) * rs[k] + rh[k];
+        if (relu) v = fmaxf(v, 0.f);
+        ov[k] = from_f32<TA>(v);
+      }
+      *(uint4*)(out + o[u]) = *(const uint4*)ov;
+    }
   }
 }
 
@@ -169,6 +192,15 @@ __global__ void avgpool_kernel(const TA* __restrict__ x, TA* __restrict__ out, i
     for (int p = 0; p < HW; ++p) s += to_f32<TA>(x[(n * HW + p) * C + c]);
     out[i] = from_f32<TA>(s / (float)HW);
   }
+}
+
+// ---- fold the statistics replicas of one layer: out[i] = sum_r stats[r][i]  (i < n = 2C)
+__global__ void fold_stats_kernel(const float* __restrict__ stats, int nrep, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < nrep; ++r) s += stats[(long)r * n + i];
+  out[i] = s;
 }
 
 // ---- running statistics of every BatchNorm2d of the trunk in one launch (table built once by the host)
@@ -309,14 +341,14 @@ int gic_bn_act(const void* y, const float* stats, const float* gamma, const floa
   GIC_CHECK_ARG(y && out && gamma && beta && (stats || run_mean) && rows > 0 && count > 0, "bn_act: bad argument");
   const BnSrc by = make_src(stats, stats_nrep, gamma, beta, run_mean, run_var);
   const BnSrc br = make_src(res_stats, stats_nrep, res_gamma, res_beta, res_run_mean, res_run_var);
-  GIC_CHECK_ARG(C % 8 == 0, "bn_act: C must be a multiple of 8 (got %d)", C);
+  GIC_CHECK_ARG(C % 8 == 0 && (C & (C - 1)) == 0, "bn_act: C must be a power of two >= 8 (got %d)", C);
   const size_t lds = (size_t)4 * C * sizeof(float);
   if (dtype == DT_F32) {
     const long total = rows * (C / 4);
-    hipLaunchKernelGGL((bn_act_kernel<float>), dim3(grid1d(total, 1024)), dim3(256), lds, (hipStream_t)stream, (const float*)y, by, (const float*)res, br, 1.f / count, relu, (float*)out, (long)rows, C);
+    hipLaunchKernelGGL((bn_act_kernel<float>), dim3(grid_periodic(total, C / 4, 2048)), dim3(256), lds, (hipStream_t)stream, (const float*)y, by, (const float*)res, br, 1.f / count, relu, (float*)out, (long)rows, C);
   } else {
     const long total = rows * (C / 8);
-    hipLaunchKernelGGL((bn_act_kernel<bf16_t>), dim3(grid1d(total, 1024)), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)y, by, (const bf16_t*)res, br, 1.f / count, relu, (bf16_t*)out, (long)rows, C);
+    hipLaunchKernelGGL((bn_act_kernel<bf16_t>), dim3(grid_periodic(total, C / 8, 2048)), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)y, by, (const bf16_t*)res, br, 1.f / count, relu, (bf16_t*)out, (long)rows, C);
   }
   GIC_CHECK_LAUNCH("bn_act");
   return GIC_OK;
@@ -347,6 +379,13 @@ int gic_avgpool(const void* x, void* out, int dtype, int N, int HW, int C, void*
   else
     hipLaunchKernelGGL((avgpool_kernel<bf16_t>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, N, HW, C);
   GIC_CHECK_LAUNCH("avgpool");
+  return GIC_OK;
+}
+
+int gic_fold_stats(const float* stats, int nrep, float* out, int n, void* stream) {
+  GIC_CHECK_ARG(stats && out && nrep >= 1 && n > 0, "fold_stats: bad argument");
+  hipLaunchKernelGGL(fold_stats_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, stats, nrep, out, n);
+  GIC_CHECK_LAUNCH("fold_stats");
   return GIC_OK;
 }
 

@@ -19,6 +19,8 @@
 //    tiles that share B (weight) panels in its private L2.
 #include "gemm.h"
 
+#include <stdlib.h>
+
 namespace gic {
 
 namespace {
@@ -27,16 +29,28 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) u32x4* gptr_u4;
 
+// 16 zero bytes in global memory: the source of an LDS-DMA chunk that falls outside the operand (conv padding, M/K tails)
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+
 template <typename T> struct GlobalPtr { typedef const __attribute__((address_space(1))) T* type; };
 
-template <typename TI, typename TO, bool AKC, bool BKC, int BM, int BN, bool VEC, int EPI, bool CONV>
+// PIPE (k-contiguous, vectorised operands only): tiles reach LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPR
+// staging) into a 3-stage ring; the loads of tile k+2 are in flight under the MFMAs of tiles k and k+1 behind a COUNTED
+// s_waitcnt vmcnt and one raw s_barrier per K tile.  The LDS image is lane-linear per wave-instruction (128-byte rows, no
+// padding), so the bank-conflict fix is an XOR of the 16-byte chunk index with (row>>1)&7, applied to the per-lane SOURCE
+// address on the way in and to the ds_read_b128 address on the way out.
+template <typename TI, typename TO, bool AKC, bool BKC, int BM, int BN, bool VEC, int EPI, bool CONV, bool PIPE>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k_tiles_per_split) {
   static_assert(!CONV || (AKC && BKC && VEC), "the implicit-GEMM convolution loader is k-contiguous and vectorised");
+  static_assert(!PIPE || (AKC && BKC && VEC), "the LDS-DMA pipeline needs k-contiguous 16-byte chunks");
   constexpr int SZ = sizeof(TI);
   constexpr int BK = 128 / SZ;          // K elements per tile
   constexpr int VE = 16 / SZ;           // elements per 16-byte chunk
-  constexpr int SA = AKC ? 144 : BM * SZ + 16;   // LDS row stride (bytes)
-  constexpr int SB = BKC ? 144 : BN * SZ + 16;
+  constexpr int SA = PIPE ? 128 : (AKC ? 144 : BM * SZ + 16);   // LDS row stride (bytes)
+  constexpr int SB = PIPE ? 128 : (BKC ? 144 : BN * SZ + 16);
+  constexpr int NSTAGE = PIPE ? 3 : 2;
   constexpr int A_BYTES = AKC ? BM * SA : BK * SA;
   constexpr int B_BYTES = BKC ? BN * SB : BK * SB;
   constexpr int BUF_BYTES = A_BYTES + B_BYTES;
@@ -46,7 +60,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
   typedef typename GlobalPtr<TI>::type gptr_t;
 
   constexpr int EPI_BYTES = BM * (BN * (int)sizeof(TO) + 16) + 4 * (BN / 2) * 2 * 4;   // staged C tile + stats scratch
-  constexpr int SMEM_BYTES = 2 * BUF_BYTES > EPI_BYTES ? 2 * BUF_BYTES : EPI_BYTES;
+  constexpr int SMEM_BYTES = NSTAGE * BUF_BYTES > EPI_BYTES ? NSTAGE * BUF_BYTES : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -93,7 +107,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
       cv_wi0[i] = wo * d.cStride - d.cPad;
       cv_base[i] = ((long)n * d.cH + cv_hi0[i]) * d.cW + cv_wi0[i];
     }
-    const int k = blockIdx.y * k_tiles_per_split * BK + (tid & 7) * VE;
+    // PIPE: physical chunk slot tid&7 holds logical chunk (tid&7) ^ swizzle(row); the swizzle (row>>1)&7 is the same
+    // for all of a thread's rows (they are 32 apart), so the thread still owns ONE k chunk per tile.
+    const int kchunk = PIPE ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7);
+    const int k = blockIdx.y * k_tiles_per_split * BK + kchunk * VE;
     cv_c = k % d.cCin;
     const int t = k / d.cCin;
     cv_s = t % d.cKW;
@@ -203,6 +220,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
     }
   };
 
+  // ---- PIPE: one K tile -> LDS stage `buf` by LDS-DMA.  Chunk c = tid + i*256 lands at byte 16*c of the stage's A (B)
+  // image: the wave-instruction's 64 lanes write 1 KiB contiguously (wave-uniform base + lane*16).
+  auto issue = [&](int kt, int buf) {
+    if constexpr (PIPE) {
+      unsigned char* sA = smem + buf * BUF_BYTES;
+      unsigned char* sB = sA + A_BYTES;
+      const int k0 = kt * BK;
+      const int kc = ((tid & 7) ^ ((tid >> 4) & 7)) * VE;         // logical k offset of this thread's chunk
+      const int wbase = (tid & ~63) * 16;
+#pragma unroll
+      for (int i = 0; i < CA; ++i) {
+        const int c = tid + i * 256;
+        const TI* src = (const TI*)g_zero16;
+        if constexpr (CONV) {
+          const int hi = cv_hi0[i] + cv_r, wi = cv_wi0[i] + cv_s;
+          if (cv_r < d.cKH && hi >= 0 && hi < d.cH && wi >= 0 && wi < d.cW)
+            src = (const TI*)d.A + (cv_base[i] + (long)cv_r * d.cW + cv_s) * d.cCin + cv_c;
+        } else {
+          const int m = bm0 + (c >> 3), k = k0 + kc;
+          if (m < M && k < K) src = (const TI*)d.A + (long)m * lda + k;
+        }
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)(sA + i * 4096 + wbase), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < CB; ++i) {
+        const int c = tid + i * 256;
+        const TI* src = (const TI*)g_zero16;
+        const int n = bn0 + (c >> 3), k = k0 + kc;
+        if (n < N && k < K) src = (const TI*)d.B + (long)n * ldb + k;
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)(sB + i * 4096 + wbase), 16, 0, 0);
+      }
+      if constexpr (CONV) {
+        cv_c += BK;
+        while (cv_c >= d.cCin) {
+          cv_c -= d.cCin;
+          if (++cv_s == d.cKW) { cv_s = 0; ++cv_r; }
+        }
+      }
+    }
+  };
+
   auto compute = [&](int buf) {
     const unsigned char* sA = smem + buf * BUF_BYTES;
     const unsigned char* sB = sA + A_BYTES;
@@ -213,7 +271,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
           const int r0 = wr * (BM / 2) + t * 16;
-          if constexpr (AKC) {
+          if constexpr (PIPE) {
+            fa[t] = *(const bf16x8*)(sA + (r0 + lr) * 128 + (((ks * 4 + lg) ^ (((r0 + lr) >> 1) & 7)) << 4));
+          } else if constexpr (AKC) {
             fa[t] = *(const bf16x8*)(sA + (r0 + lr) * SA + ks * 64 + lg * 16);
           } else {
             // [k][m] image: lane (q=lr>>2, p=lr&3) addresses row k0+q, cols 4p..4p+3; receives column lr
@@ -226,7 +286,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
           const int r0 = wc * (BN / 2) + t * 16;
-          if constexpr (BKC) {
+          if constexpr (PIPE) {
+            fb[t] = *(const bf16x8*)(sB + (r0 + lr) * 128 + (((ks * 4 + lg) ^ (((r0 + lr) >> 1) & 7)) << 4));
+          } else if constexpr (BKC) {
             fb[t] = *(const bf16x8*)(sB + (r0 + lr) * SB + ks * 64 + lg * 16);
           } else {
             const unsigned char* p0 = sB + (ks * 32 + lg * 8 + (lr >> 2)) * SB + (r0 + 4 * (lr & 3)) * 2;
@@ -249,8 +311,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
       for (int t = 0; t < TM; ++t) {
         const int r0 = wr * (BM / 2) + t * 16;
         if constexpr (AKC) {
-          const float4 v0 = *(const float4*)(sA + (r0 + lr) * SA + lg * 32);
-          const float4 v1 = *(const float4*)(sA + (r0 + lr) * SA + lg * 32 + 16);
+          const int sw = PIPE ? (((r0 + lr) >> 1) & 7) : 0;
+          const float4 v0 = *(const float4*)(sA + (r0 + lr) * SA + (((2 * lg) ^ sw) << 4));
+          const float4 v1 = *(const float4*)(sA + (r0 + lr) * SA + (((2 * lg + 1) ^ sw) << 4));
           fa[t][0] = v0.x; fa[t][1] = v0.y; fa[t][2] = v0.z; fa[t][3] = v0.w;
           fa[t][4] = v1.x; fa[t][5] = v1.y; fa[t][6] = v1.z; fa[t][7] = v1.w;
         } else {
@@ -262,8 +325,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
       for (int t = 0; t < TN; ++t) {
         const int r0 = wc * (BN / 2) + t * 16;
         if constexpr (BKC) {
-          const float4 v0 = *(const float4*)(sB + (r0 + lr) * SB + lg * 32);
-          const float4 v1 = *(const float4*)(sB + (r0 + lr) * SB + lg * 32 + 16);
+          const int sw = PIPE ? (((r0 + lr) >> 1) & 7) : 0;
+          const float4 v0 = *(const float4*)(sB + (r0 + lr) * SB + (((2 * lg) ^ sw) << 4));
+          const float4 v1 = *(const float4*)(sB + (r0 + lr) * SB + (((2 * lg + 1) ^ sw) << 4));
           fb[t][0] = v0.x; fb[t][1] = v0.y; fb[t][2] = v0.z; fb[t][3] = v0.w;
           fb[t][4] = v1.x; fb[t][5] = v1.y; fb[t][6] = v1.z; fb[t][7] = v1.w;
         } else {
@@ -285,7 +349,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
   const int nk = (K + BK - 1) / BK;
   const int kt0 = blockIdx.y * k_tiles_per_split;
   const int kt1 = min(nk, kt0 + k_tiles_per_split);
-  if (kt0 < kt1) {
+  if constexpr (PIPE) {
+    if (kt0 < kt1) {
+      constexpr int NL = CA + CB;                       // LDS-DMA instructions per thread per stage
+      issue(kt0, 0);
+      if (kt0 + 1 < kt1) issue(kt0 + 1, 1);
+      int buf = 0;
+      for (int kt = kt0; kt < kt1; ++kt) {
+        // stage kt has landed once all but this wave's newest NL DMAs (stage kt+1) are done; the barrier then
+        // publishes every wave's part of it and retires all reads of the stage that is about to be refilled.
+        if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < kt1) issue(kt + 2, buf >= 1 ? buf - 1 : 2);      // (buf + 2) % 3
+        compute(buf);
+        buf = buf == 2 ? 0 : buf + 1;
+      }
+      __syncthreads();                                  // all fragment reads done before the epilogue reuses LDS
+    }
+  } else if (kt0 < kt1) {
     int cur = 0;
     gload(kt0);
     sstore(kt0, 0);
@@ -434,7 +516,7 @@ int launch(const GemmDesc& d, hipStream_t stream) {
   // split-K only where the tile grid leaves most of the 256 CUs idle and K is deep enough to share
   int splits = 1;
   // (bf16 compute mode only: the f32 parity mode stays bit-reproducible run to run, atomics reorder the f32 sum)
-  if (EPI == EPI_PLAIN && sizeof(TI) == 2 && sizeof(TO) == 4 && tiles < 96 && nk >= 8) {
+  if (EPI == EPI_PLAIN && sizeof(TI) == 2 && sizeof(TO) == 4 && tiles < 24 && nk >= 8) {
     splits = 256 / tiles;
     if (splits > nk / 2) splits = nk / 2;
     if (splits > 16) splits = 16;
@@ -447,16 +529,35 @@ int launch(const GemmDesc& d, hipStream_t stream) {
     const int g = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
     hipLaunchKernelGGL(zero2d_kernel, dim3(g), dim3(256), 0, stream, (float*)d.C, d.ldc, d.M, d.N);
   }
-  hipLaunchKernelGGL((gemm_kernel<TI, TO, AKC, BKC, BM, BN, VEC, EPI, CONV>), dim3(tiles, splits), dim3(256), 0, stream, d, per);
+  // LDS-DMA ring (PIPE) vs register staging: the ring hides load latency when a CU holds ONE block (grid <= ~2 blocks
+  // per CU) and K is deep; with many blocks per CU the register-staged kernel wins (2 co-resident blocks, 72 KB LDS each)
+  // and for K of one or two tiles the ring's prologue is pure overhead.  Measured on MI355X (tools/gemm_bench.py).
+  constexpr bool CAN_PIPE = AKC && BKC && VEC;
+  const bool pipe = CAN_PIPE && per >= 6 && (long)tiles * splits <= 2 * 256 + 8 && !getenv("GIC_GEMM_NO_PIPE");
+  if constexpr (CAN_PIPE) {
+    if (pipe) {
+      hipLaunchKernelGGL((gemm_kernel<TI, TO, AKC, BKC, BM, BN, VEC, EPI, CONV, true>), dim3(tiles, splits), dim3(256), 0, stream, d, per);
+      GIC_CHECK_LAUNCH("gemm");
+      return GIC_OK;
+    }
+  }
+  hipLaunchKernelGGL((gemm_kernel<TI, TO, AKC, BKC, BM, BN, VEC, EPI, CONV, false>), dim3(tiles, splits), dim3(256), 0, stream, d, per);
   GIC_CHECK_LAUNCH("gemm");
   return GIC_OK;
+}
+
+// 128x128 tiles only when there are enough of them to co-schedule two blocks per CU (latency hiding by TLP);
+// GIC_GEMM_BIG_MIN overrides the threshold for tuning runs.
+int big_tile_min() {
+  static const int v = [] { const char* e = getenv("GIC_GEMM_BIG_MIN"); return e ? atoi(e) : 192; }();
+  return v;
 }
 
 template <typename TI, typename TO, bool AKC, bool BKC, int EPI>
 int pick_tile(const GemmDesc& d, bool vec, hipStream_t stream) {
   // 128x128 tiles when they still give >= ~1 block per CU, else 64x64.
   const long big_tiles = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
-  const bool big = big_tiles >= 192 && d.M >= 128 && d.N >= 128;
+  const bool big = big_tiles >= big_tile_min() && d.M >= 128 && d.N >= 128;
   if (big) {
     return vec ? launch<TI, TO, AKC, BKC, 128, 128, true, EPI>(d, stream)
                : launch<TI, TO, AKC, BKC, 128, 128, false, EPI>(d, stream);
@@ -479,7 +580,7 @@ int pick_layout(const GemmDesc& d, bool vec, hipStream_t stream) {
 template <typename TI, typename TO, int EPI>
 int pick_conv(const GemmDesc& d, hipStream_t stream) {
   const long big_tiles = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
-  if (big_tiles >= 192 && d.N >= 128) return launch<TI, TO, true, true, 128, 128, true, EPI, true>(d, stream);
+  if (big_tiles >= big_tile_min() && d.N >= 128) return launch<TI, TO, true, true, 128, 128, true, EPI, true>(d, stream);
   return launch<TI, TO, true, true, 64, 64, true, EPI, true>(d, stream);
 }
 

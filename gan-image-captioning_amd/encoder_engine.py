@@ -19,7 +19,7 @@ from . import engine
 from .engine import ptr, stream_ptr
 
 AVAILABLE = True
-STATS_REPLICAS = 16      # BatchNorm sum replicas: conv workgroup b adds into replica b % 16 (global f32 atomics serialise per address)
+STATS_REPLICAS = 8       # BatchNorm sum replicas: conv workgroup b adds into replica b % 16 (global f32 atomics serialise per address)
 
 
 def _check(status, what):
@@ -27,12 +27,13 @@ def _check(status, what):
 
 
 class _ConvStep:
-    __slots__ = ("conv", "bn", "cin", "cout", "k", "stride", "pad", "stats_off", "w", "name")
+    __slots__ = ("conv", "bn", "cin", "cout", "k", "stride", "pad", "stats_off", "fold_off", "w", "name")
 
     def __init__(self, name, conv, bn):
         self.name, self.conv, self.bn = name, conv, bn
         self.cin, self.cout, self.k, self.stride, self.pad = conv.cin, conv.cout, conv.k, conv.stride, conv.pad
         self.stats_off = 0
+        self.fold_off = 0
         self.w = None
 
 
@@ -52,13 +53,15 @@ class TrunkPlan:
         self.steps: List[_ConvStep] = [self.stem]
         for b in self.blocks:
             self.steps += [s for s in (b["c1"], b["c2"], b["c3"], b["ds"]) if s is not None]
-        off = 0
+        off = foff = 0
         for s in self.steps:
-            s.stats_off = off
+            s.stats_off, s.fold_off = off, foff
             off += 2 * s.cout * STATS_REPLICAS
-        self.stats_len = off
+            foff += 2 * s.cout
+        self.stats_len, self.fold_len = off, foff
         self._wkey = None
         self._bufs: Dict[Tuple[int, int], dict] = {}
+        self._folded = None
         self.pending_tracked = 0
 
     def sync_counters(self) -> None:
@@ -92,7 +95,8 @@ class TrunkPlan:
         if key in self._bufs:
             return self._bufs[key]
         act = self.act
-        b: dict = {"stats": torch.zeros(self.stats_len, device=dev, dtype=torch.float32)}
+        b: dict = {"stats": torch.zeros(self.stats_len, device=dev, dtype=torch.float32),
+                   "folded": torch.zeros(self.fold_len, device=dev, dtype=torch.float32)}
         b["xin"] = torch.empty(N, S + 6, S + 6, 4, device=dev, dtype=act)
         h = (S + 6 - 7) // 2 + 1
         b["y0"] = torch.empty(N, h, h, 64, device=dev, dtype=act)
@@ -131,13 +135,13 @@ class TrunkPlan:
         # device table for the one-launch running-statistics update
         table = (L.BnRunningDesc * len(self.steps))()
         for i, s in enumerate(self.steps):
-            table[i].stats = b["stats"].data_ptr() + 4 * s.stats_off
+            table[i].stats = b["folded"].data_ptr() + 4 * s.fold_off
             table[i].running_mean = s.bn.running_mean.data_ptr()
             table[i].running_var = s.bn.running_var.data_ptr()
             table[i].count = float(rows[s.name])
             table[i].momentum = float(s.bn.momentum)
             table[i].C = s.cout
-            table[i].nrep = STATS_REPLICAS
+            table[i].nrep = 1
         raw = bytes(table)
         b["table"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self._bufs[key] = b
@@ -148,6 +152,8 @@ class TrunkPlan:
         st = None if stats is None else stats.data_ptr() + 4 * s.stats_off
         _check(L.load().gic_conv2d(ptr(x), ptr(s.w), ptr(y), st, STATS_REPLICAS, self.dtype, N, H, W, cin if cin is not None else s.cin, s.cout, s.k,
                                    kw if kw is not None else s.k, s.stride, pad if pad is not None else s.pad, stream_ptr()), "gic_conv2d " + s.name)
+        if stats is not None and self._folded is not None:       # fold the replicas once; consumers read [2C]
+            _check(L.load().gic_fold_stats(st, STATS_REPLICAS, self._folded.data_ptr() + 4 * s.fold_off, 2 * s.cout, stream_ptr()), "gic_fold_stats")
 
     def _bn_args(self, s: Optional[_ConvStep], stats: Optional[torch.Tensor], training: bool):
         """(stats, gamma, beta, run_mean, run_var) pointers of one BatchNorm; all None for 'no BN'."""
@@ -155,13 +161,13 @@ class TrunkPlan:
             return (None,) * 5
         g, b = ptr(s.bn.weight.detach()), ptr(s.bn.bias.detach())
         if training:
-            return (stats.data_ptr() + 4 * s.stats_off, g, b, None, None)
+            return (self._folded.data_ptr() + 4 * s.fold_off, g, b, None, None)
         return (None, g, b, ptr(s.bn.running_mean), ptr(s.bn.running_var))
 
     def _bn_act(self, s, y, out, stats, training, rows, relu=True, res=None, res_step=None):
         a = self._bn_args(s, stats, training)
         r = self._bn_args(res_step, stats, training)
-        _check(L.load().gic_bn_act(ptr(y), *a, ptr(res), *r, STATS_REPLICAS, float(rows), int(relu), ptr(out), self.dtype, rows, s.cout, stream_ptr()),
+        _check(L.load().gic_bn_act(ptr(y), *a, ptr(res), *r, 1, float(rows), int(relu), ptr(out), self.dtype, rows, s.cout, stream_ptr()),
                "gic_bn_act " + s.name)
 
     def forward(self, images: torch.Tensor, training: bool) -> torch.Tensor:
@@ -177,6 +183,7 @@ class TrunkPlan:
         self._pack_weights(dev)
         b = self._buffers(N, S, dev)
         stats = b["stats"] if training else None
+        self._folded = b["folded"] if training else None
         if training:
             b["stats"].zero_()
         rows = b["rows"]
@@ -185,7 +192,7 @@ class TrunkPlan:
         self._conv(self.stem, b["xin"], b["y0"], stats, N, S + 6, S + 6, cin=4, kw=8, pad=0)
         h = b["y0"].shape[1]
         a = self._bn_args(self.stem, stats, training)
-        _check(lib.gic_bn_relu_maxpool(ptr(b["y0"]), *a, STATS_REPLICAS, float(rows[self.stem.name]), ptr(b["x0"]), self.dtype, N, h, h, 64, stream_ptr()),
+        _check(lib.gic_bn_relu_maxpool(ptr(b["y0"]), *a, 1, float(rows[self.stem.name]), ptr(b["x0"]), self.dtype, N, h, h, 64, stream_ptr()),
                "gic_bn_relu_maxpool")
         x = b["x0"]
         for blk, e in zip(self.blocks, b["blocks"]):
@@ -298,9 +305,12 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops):
         if key not in seen:
             seen[key] = [event_time_ms(lambda: plan._conv(s, xi, yo, None, N, H, W, **kw), 5, stream), 0, macs, s.name]
         seen[key][1] += 1
+    import sys
     for key, (ms, count, macs, name) in seen.items():
         total_ms += ms * count
         total_flops += 2.0 * macs * count
+        print(f"[conv] {name:22s} Cin={key[0]:5d} Cout={key[1]:5d} k={key[2]} s={key[3]} H={key[4]:4d} x{count}: {ms * 1e3:8.1f} us "
+              f"{2.0 * macs / (ms * 1e-3) / 1e12:7.1f} TFLOP/s", file=sys.stderr)
         if best is None or ms * count > best[0] * best[1]:
             best = (ms, count, macs, name, key)
     ms, count, macs, name, key = best
