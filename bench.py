@@ -95,7 +95,13 @@ def roofline_probe(inst, args, cgan):
     dev = args.device
     if cgan:
         from gan_image_captioning_amd import encoder_engine
-        return encoder_engine.roofline_probe(inst.gen.encoder, args, event_time_ms, MFMA_BF16_PEAK_TFLOPS)
+        traffic = None
+        try:     # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json; see its "source")
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                traffic = json.load(fh)["conv_bnstats"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+        return encoder_engine.roofline_probe(inst.gen.encoder, args, event_time_ms, MFMA_BF16_PEAK_TFLOPS, traffic)
     # discriminator highway GEMM: [B*64, 904] x [900, 904]^T, bf16 MFMA, fused gate+dropout epilogue is separate;
     # the plain GEMM of the same shape is the dominant launch without the encoder.
     den = inst.disc.engine()

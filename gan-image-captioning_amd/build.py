@@ -29,6 +29,18 @@ def _stale(target: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile what is stale.  An exclusive file lock serialises concurrent callers (one rank per GPU under torchrun)."""
+    import fcntl
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    with open(os.path.join(CSRC, "build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [
         os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "gicap.h")]

@@ -1,0 +1,111 @@
+"""CPU checks of the host-side mirror of the reference interface (no compute): CLI flags, batch contract, module
+surface / state-dict keys, schedules, error behaviour."""
+import json
+import os
+
+import pytest
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_every_reference_flag_kept_with_type_and_default():
+    """tests/golden/reference_flags.json is dumped from the reference's own parser (oracle/make_flag_fixture.py)."""
+    from gan_image_captioning_amd.args import build_parser
+    ref = json.load(open(os.path.join(GOLDEN, "reference_flags.json")))
+    mine = {a.option_strings[0]: a for a in build_parser()._actions if a.option_strings and a.dest != "help"}
+    assert len(ref) == 40
+    for flag, spec in ref.items():
+        assert flag in mine, f"reference flag {flag} missing"
+        act = mine[flag]
+        assert act.dest == spec["dest"]
+        assert act.default == spec["default"], flag
+        if spec["type"] == "list":       # reference: type=list (args.py:44-52), usable only at the default
+            assert act.type(spec["default"]) == spec["default"] and act.type("3,4,5") == [3, 4, 5]
+        else:
+            assert getattr(act.type, "__name__", None) == spec["type"], flag
+        assert (list(act.choices) if act.choices else None) == spec["choices"]
+
+
+def test_get_args_side_effects(tmp_path):
+    """args.py:261-278: fresh <save_dir>/<expt>_<n>/models, log file path, device resolved."""
+    from gan_image_captioning_amd.args import get_args
+    a1 = get_args(["--save-dir", str(tmp_path), "--expt-name", "e", "--device", "cpu"])
+    a2 = get_args(["--save-dir", str(tmp_path), "--expt-name", "e", "--device", "cpu"])
+    assert a1.expt_name == "e_1" and a2.expt_name == "e_2"
+    assert os.path.isdir(a1.model_dir) and a1.model_dir.endswith(os.path.join("e_1", "models"))
+    assert a1.log_file == os.path.join(str(tmp_path), "e_1", "log")
+    assert a1.device == torch.device("cpu")
+    assert a1.temperature == 100 and isinstance(a1.temperature, int)            # args.py:180-183: type int
+
+
+def test_collate_fn_batch_contract():
+    """tasks.py:138-158: [<S>] + tokens + [<E>] + PAD, lengths = len+2, max_caption_len = longest+2."""
+    from gan_image_captioning_amd.tasks import collate_fn
+    batch = [(torch.full((3, 8, 8), 1.0), [5, 6, 7]), (torch.full((3, 8, 8), 2.0), [9])]
+    images, caps, lengths, L = collate_fn(batch)
+    assert images.shape == (2, 3, 8, 8) and images.dtype == torch.float32
+    assert L == 5 and caps.dtype == torch.long and lengths.dtype == torch.int32
+    assert caps.tolist() == [[1, 5, 6, 7, 2], [1, 9, 2, 0, 0]]
+    assert lengths.tolist() == [5, 3]
+
+
+def test_synthetic_dataset_matches_contract():
+    from gan_image_captioning_amd.tasks import SyntheticCaptionData, collate_fn, synthetic_batch
+    ds = SyntheticCaptionData(6, vocab_size=50, image_size=16, caption_len=10, seed=3)
+    img, toks = ds[2]
+    img2, toks2 = ds[2]
+    assert torch.equal(img, img2) and toks == toks2 and len(toks) == 8 and min(toks) >= 4 and max(toks) < 50
+    images, caps, lengths, L = collate_fn([ds[i] for i in range(6)])
+    assert L == 10 and caps[:, 0].eq(1).all() and caps[:, -1].eq(2).all() and lengths.eq(10).all()
+    ragged = SyntheticCaptionData(8, 50, 16, 10, seed=3, ragged=True)
+    _, rc, rl, rL = collate_fn([ragged[i] for i in range(8)])
+    assert rL == int(rl.max()) and (rc == 0).any()
+    _, c, l, LL = synthetic_batch(4, 50, 16, 12, seed=1, with_images=False)
+    assert c.shape == (4, 12) and LL == 12 and c[:, 0].eq(1).all() and c[:, -1].eq(2).all()
+
+
+def test_module_surface_and_state_dict_keys():
+    from gan_image_captioning_amd.args import default_args
+    from gan_image_captioning_amd.discriminator import Discriminator
+    from gan_image_captioning_amd.generator import Generator
+    a = default_args(vocab_size=50, gen_num_layers=2, device="cpu")
+    gen, disc = Generator(a), Discriminator(a)
+    gk, dk = set(gen.state_dict()), set(disc.state_dict())
+    for k in ("decoder.embed.weight", "decoder.lstm.weight_ih_l0", "decoder.lstm.weight_hh_l1", "decoder.lstm.bias_ih_l1",
+              "decoder.lstm.bias_hh_l0", "decoder.linear.weight", "decoder.linear.bias", "encoder.linear.weight", "encoder.bn.weight",
+              "encoder.bn.running_mean", "encoder.bn.num_batches_tracked", "encoder.resnet.0.weight", "encoder.resnet.1.running_var",
+              "encoder.resnet.4.0.conv1.weight", "encoder.resnet.5.0.downsample.0.weight", "encoder.resnet.5.0.downsample.1.bias",
+              "encoder.resnet.7.1.bn2.weight"):
+        assert k in gk, k
+    assert dk == {"embeddings.weight", "convs.0.weight", "convs.0.bias", "convs.1.weight", "convs.1.bias", "convs.2.weight",
+                  "convs.2.bias", "highway.weight", "highway.bias", "feature2out.weight", "feature2out.bias", "out2logits.weight",
+                  "out2logits.bias"}
+    assert disc.state_dict()["convs.1.weight"].shape == (300, 1, 4, 1) and disc.state_dict()["embeddings.weight"].shape == (64, 50)
+    assert gen.decoder.temperature == 100 and hasattr(gen.decoder, "sample") and hasattr(gen.decoder, "embed")
+    # init_params: U(-0.05, 0.05) over every tensor incl. biases, BN affine and trunk convs (generator.py:116-123)
+    for p in list(gen.parameters()) + list(disc.parameters()):
+        assert float(p.detach().abs().max()) <= 0.05 + 1e-7
+    assert gen.encoder.bn.momentum == 0.01
+
+
+def test_losses_schedules_and_errors_mirror_reference():
+    from gan_image_captioning_amd import utils
+    g = json.load(open(os.path.join(GOLDEN, "reference_flags.json")))
+    assert g["--adv-loss-type"]["default"] == "standard"
+    with pytest.raises(NotImplementedError):
+        utils.get_losses(None, None, None, "wasserstein")
+    with pytest.raises(Exception, match="Unknown adapt type"):
+        utils.get_fixed_temperature(100, 1, 30, "cubic")
+    assert utils.get_fixed_temperature(100, 25, 50, "exp") == pytest.approx(10.0)
+    assert utils.get_fixed_temperature(100, 3, 30, "no") == 1.0
+
+
+def test_product_path_has_no_oracle_import():
+    """The oracle is test infrastructure: nothing under the package may import it."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gan-image-captioning_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
