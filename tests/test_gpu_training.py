@@ -1,0 +1,102 @@
+"""GPU tests of the trainer around the hot path: the MLE pre-train step against the reference's
+golden vectors, the `main` entry point on synthetic data (adversarial epoch, validation pass, checkpoint in the
+reference's format), and checkpoint round-trips."""
+import os
+
+import pytest
+import torch
+
+from tests.golden_io import Golden
+from tests.gpu_util import close, dec_param_names
+
+pytestmark = pytest.mark.gpu
+
+
+def _instructor(**over):
+    from gan_image_captioning_amd.args import default_args
+    from gan_image_captioning_amd.training import GANInstructor
+    kw = dict(device="cuda", log_file=None, model_dir=None, save_dir=None, compute_dtype="fp32")
+    kw.update(over)
+    args = default_args(**kw)
+    return GANInstructor(args, None, None), args
+
+
+def test_pretrain_step_matches_reference():
+    """genpretrain_loop body (training.py:53-95): free-running sample(pretrain=True) + CrossEntropyLoss over all
+    positions incl. PAD + clip + Adam(lr=1e-2), two steps, vs the reference's own run (pretrain_tiny.npz)."""
+    g = Golden("pretrain_tiny")
+    m = g.meta
+    inst, args = _instructor(vocab_size=m["V"], gen_embed_dim=m["E"], gen_hidden_dim=m["H"], gen_num_layers=m["NL"],
+                             pretrain_lr=m["pretrain_lr"], clip_norm=m["clip"])
+    names = dec_param_names(m["NL"])
+    gp = g.group("gp0/")
+    with torch.no_grad():
+        for n, p in zip(names, inst.gen.decoder.param_list()):
+            p.copy_(gp[n])
+    caps = g.t("caps").to(args.device)
+    inst.gen.train()
+    for step in range(m["steps"]):
+        loss = inst.pretrain_step(None, caps, m["L"], train=True)
+        torch.cuda.synchronize()
+        pre = f"s{step}/"
+        assert float(loss) == pytest.approx(float(g.t(pre + "loss")), rel=1e-5 if step == 0 else 2e-3)
+        assert float(inst.pretrain_opt.grad_norm) == pytest.approx(float(g.t(pre + "g_norm")), rel=1e-4 if step == 0 else 2e-2)
+        if step == 0:
+            for n, p in zip(names, inst.gen.decoder.param_list()):
+                close(p.grad, g.t(pre + "grad/" + n), rtol=2e-3, atol_scale=1e-4, what=n)
+        for n, p in zip(names, inst.gen.decoder.param_list()):
+            # Adam at lr=1e-2 moves every entry by <= lr; near-zero gradients make the sign noise-sensitive
+            assert float((p.detach().cpu() - g.t(pre + "post/" + n)).abs().max()) <= 1.05 * m["pretrain_lr"] * (step + 1), n
+    assert int(inst.pretrain_opt.step_count) == m["steps"] and int(inst.gen_opt.step_count) == 0
+
+
+@pytest.mark.parametrize("cgan", [0, 1])
+def test_main_entry_runs_an_epoch_and_writes_reference_format_checkpoint(tmp_path, cgan):
+    from gan_image_captioning_amd.main import main
+    argv = ["--synthetic", "1", "--synthetic-batches", "3", "--synthetic-caption-len", "8", "--vocab-size", "64",
+            "--adv-train-batch-size", "4", "--adv-eval-batch-size", "4", "--adv-epochs", "1", "--pretrain-epochs", "1",
+            "--pre-train-batch-size", "4", "--pre-eval-batch-size", "4", "--gen-hidden-dim", "32", "--gen-embed-dim", "16",
+            "--image-size", "32", "--conditional-gan", str(cgan), "--encoder-arch", "resnet18", "--save-dir", str(tmp_path),
+            "--expt-name", "t", "--num-workers", "0", "--compute-dtype", "bf16"]
+    inst = main(argv)
+    torch.cuda.synchronize()
+    assert inst.gen_steps == 3 + 1 and inst.disc_steps == inst.gen_steps           # 3 train + 1 val batches
+    assert int(inst.gen_opt.step_count) == 3 and int(inst.disc_opt.step_count) == 3 and int(inst.pretrain_opt.step_count) == 3
+    # temperature was advanced after every batch, val included (training.py:183)
+    assert inst.gen.decoder.temperature == pytest.approx(100 ** ((0 + 1 / 1) / 1))
+    mdir = os.path.join(str(tmp_path), "t_1", "models")
+    adv = torch.load(os.path.join(mdir, "adv_model.ckpt"), map_location="cpu")
+    assert set(adv) == {"generator", "discriminator"}                              # training.py:225-226
+    assert "decoder.lstm.weight_ih_l0" in adv["generator"] and "encoder.resnet.4.0.conv1.weight" in adv["generator"]
+    assert set(adv["discriminator"]) == set(inst.disc.state_dict())
+    pre = torch.load(os.path.join(mdir, "pretrained_model.ckpt"), map_location="cpu")   # training.py:118
+    assert set(pre) == set(inst.gen.state_dict())
+    for v in adv["generator"].values():
+        assert torch.isfinite(v.float()).all()
+    if cgan:
+        assert int(adv["generator"]["encoder.resnet.1.num_batches_tracked"]) > 0
+        assert float(adv["generator"]["encoder.resnet.1.running_var"].sub(1).abs().max()) > 0
+    assert os.path.getsize(os.path.join(str(tmp_path), "t_1", "log.txt")) > 0
+
+
+def test_checkpoint_roundtrip_reproduces_the_step():
+    g = Golden("tiny")
+    m = g.meta
+    kw = dict(vocab_size=m["V"], gen_embed_dim=m["E"], gen_hidden_dim=m["H"], gen_num_layers=m["NL"], disc_num_filters=m["nf"])
+    a, args = _instructor(**kw)
+    b, _ = _instructor(**kw)
+    b.gen.load_state_dict(a.gen.state_dict())
+    b.disc.load_state_dict(a.disc.state_dict())
+    caps = g.t("caps").to(args.device)
+    u = g.t("s0/u").to(args.device)
+    masks = [k.to(args.device) for k in g.masks(0)]
+    outs = []
+    for inst in (a, b):
+        inst.gen.train(); inst.disc.train()
+        o = inst.fused(None, caps, m["L"], True, u, masks)
+        torch.cuda.synchronize()
+        outs.append((o["losses"].cpu(), o["ids"].cpu(), inst.gen_arena.flat.cpu().clone(), inst.disc_arena.flat.cpu().clone()))
+    assert torch.equal(outs[0][1], outs[1][1])
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-6, atol=0)
+    torch.testing.assert_close(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(outs[0][3], outs[1][3], rtol=1e-5, atol=1e-7)
