@@ -94,7 +94,7 @@ template <typename TA> struct Vec16 { static constexpr int N = 16 / sizeof(TA); 
 
 // ---- out = [relu]( bn(y) + (res ? bn_res(res) : 0) ), rows x C; 16 bytes (8 bf16 / 4 f32 channels) per access
 template <typename TA>
-__global__ __launch_bounds__(256) void bn_act_kernel(const TA* __restrict__ y, BnSrc by, const TA* __restrict__ res, BnSrc br,
+__global__ __launch_bounds__(1024) void bn_act_kernel(const TA* __restrict__ y, BnSrc by, const TA* __restrict__ res, BnSrc br,
                                                       float inv_count, int relu, TA* __restrict__ out, long rows, int C) {
   extern __shared__ __attribute__((aligned(16))) float coef[];      // [4][C]
   constexpr int VN = Vec16<TA>::N;
@@ -273,6 +273,12 @@ inline int grid1d(long total, int cap = 4096) {
   long g = (total + 255) / 256;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
+// bn_act: 1024-thread blocks, at most 2 per CU: few blocks fold the statistics replicas (the per-block prologue), and
+// gridDim.x*1024 stays a multiple of every power-of-two channel-group count <= 1024 (threads keep one channel group).
+inline int bn_act_grid(long total) {
+  long g = (total + 1023) / 1024;
+  return (int)(g < 1 ? 1 : (g > 512 ? 512 : g));
+}
 // grid whose total thread count is a multiple of `period` work items (period = C/4, a power of two here)
 inline int grid_periodic(long total, int period, int cap = 4096) {
   int g = grid1d(total, cap);
@@ -345,10 +351,10 @@ int gic_bn_act(const void* y, const float* stats, const float* gamma, const floa
   const size_t lds = (size_t)4 * C * sizeof(float);
   if (dtype == DT_F32) {
     const long total = rows * (C / 4);
-    hipLaunchKernelGGL((bn_act_kernel<float>), dim3(grid_periodic(total, C / 4, 2048)), dim3(256), lds, (hipStream_t)stream, (const float*)y, by, (const float*)res, br, 1.f / count, relu, (float*)out, (long)rows, C);
+    hipLaunchKernelGGL((bn_act_kernel<float>), dim3(bn_act_grid(total)), dim3(1024), lds, (hipStream_t)stream, (const float*)y, by, (const float*)res, br, 1.f / count, relu, (float*)out, (long)rows, C);
   } else {
     const long total = rows * (C / 8);
-    hipLaunchKernelGGL((bn_act_kernel<bf16_t>), dim3(grid_periodic(total, C / 8, 2048)), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)y, by, (const bf16_t*)res, br, 1.f / count, relu, (bf16_t*)out, (long)rows, C);
+    hipLaunchKernelGGL((bn_act_kernel<bf16_t>), dim3(bn_act_grid(total)), dim3(1024), lds, (hipStream_t)stream, (const bf16_t*)y, by, (const bf16_t*)res, br, 1.f / count, relu, (bf16_t*)out, (long)rows, C);
   }
   GIC_CHECK_LAUNCH("bn_act");
   return GIC_OK;

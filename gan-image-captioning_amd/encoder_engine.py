@@ -135,13 +135,13 @@ class TrunkPlan:
         # device table for the one-launch running-statistics update
         table = (L.BnRunningDesc * len(self.steps))()
         for i, s in enumerate(self.steps):
-            table[i].stats = b["folded"].data_ptr() + 4 * s.fold_off
+            table[i].stats = b["stats"].data_ptr() + 4 * s.stats_off
             table[i].running_mean = s.bn.running_mean.data_ptr()
             table[i].running_var = s.bn.running_var.data_ptr()
             table[i].count = float(rows[s.name])
             table[i].momentum = float(s.bn.momentum)
             table[i].C = s.cout
-            table[i].nrep = 1
+            table[i].nrep = STATS_REPLICAS
         raw = bytes(table)
         b["table"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self._bufs[key] = b
@@ -152,8 +152,6 @@ class TrunkPlan:
         st = None if stats is None else stats.data_ptr() + 4 * s.stats_off
         _check(L.load().gic_conv2d(ptr(x), ptr(s.w), ptr(y), st, STATS_REPLICAS, self.dtype, N, H, W, cin if cin is not None else s.cin, s.cout, s.k,
                                    kw if kw is not None else s.k, s.stride, pad if pad is not None else s.pad, stream_ptr()), "gic_conv2d " + s.name)
-        if stats is not None and self._folded is not None:       # fold the replicas once; consumers read [2C]
-            _check(L.load().gic_fold_stats(st, STATS_REPLICAS, self._folded.data_ptr() + 4 * s.fold_off, 2 * s.cout, stream_ptr()), "gic_fold_stats")
 
     def _bn_args(self, s: Optional[_ConvStep], stats: Optional[torch.Tensor], training: bool):
         """(stats, gamma, beta, run_mean, run_var) pointers of one BatchNorm; all None for 'no BN'."""
@@ -161,13 +159,13 @@ class TrunkPlan:
             return (None,) * 5
         g, b = ptr(s.bn.weight.detach()), ptr(s.bn.bias.detach())
         if training:
-            return (self._folded.data_ptr() + 4 * s.fold_off, g, b, None, None)
+            return (stats.data_ptr() + 4 * s.stats_off, g, b, None, None)
         return (None, g, b, ptr(s.bn.running_mean), ptr(s.bn.running_var))
 
     def _bn_act(self, s, y, out, stats, training, rows, relu=True, res=None, res_step=None):
         a = self._bn_args(s, stats, training)
         r = self._bn_args(res_step, stats, training)
-        _check(L.load().gic_bn_act(ptr(y), *a, ptr(res), *r, 1, float(rows), int(relu), ptr(out), self.dtype, rows, s.cout, stream_ptr()),
+        _check(L.load().gic_bn_act(ptr(y), *a, ptr(res), *r, STATS_REPLICAS, float(rows), int(relu), ptr(out), self.dtype, rows, s.cout, stream_ptr()),
                "gic_bn_act " + s.name)
 
     def forward(self, images: torch.Tensor, training: bool) -> torch.Tensor:
@@ -192,7 +190,7 @@ class TrunkPlan:
         self._conv(self.stem, b["xin"], b["y0"], stats, N, S + 6, S + 6, cin=4, kw=8, pad=0)
         h = b["y0"].shape[1]
         a = self._bn_args(self.stem, stats, training)
-        _check(lib.gic_bn_relu_maxpool(ptr(b["y0"]), *a, 1, float(rows[self.stem.name]), ptr(b["x0"]), self.dtype, N, h, h, 64, stream_ptr()),
+        _check(lib.gic_bn_relu_maxpool(ptr(b["y0"]), *a, STATS_REPLICAS, float(rows[self.stem.name]), ptr(b["x0"]), self.dtype, N, h, h, 64, stream_ptr()),
                "gic_bn_relu_maxpool")
         x = b["x0"]
         for blk, e in zip(self.blocks, b["blocks"]):
