@@ -12,6 +12,7 @@ Work that the reference executes and discards is skipped (results identical, SUR
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -31,6 +32,7 @@ class FusedAdvStep:
         self._buf: Dict[tuple, dict] = {}
         self._gen_grads = None
         self._disc_grads = None
+        self.overlap = not os.environ.get("GIC_NO_STREAM_OVERLAP")
 
     # grads of the decoder parameters are views into the generator arena (order = Decoder.param_list())
     def _grad_lists(self):
@@ -53,16 +55,28 @@ class FusedAdvStep:
                 "d_feat": torch.empty(B, dec.E, device=dev, dtype=torch.float32),
                 "d_probs": torch.empty(B, L, dec.V, device=dev, dtype=dec.act),
                 "st_real": den.alloc_state(B, L, dev), "st_fake": den.alloc_state(B, L, dev), "st_gen": den.alloc_state(B, L, dev),
-                "disc_ws": den.alloc_bwd_ws(B, L, dev),
+                "disc_ws": den.alloc_bwd_ws(B, L, dev), "disc_ws_gen": den.alloc_bwd_ws(B, L, dev),
                 "logits": torch.empty(3, B * den.R, device=dev, dtype=torch.float32),
                 "ones": torch.ones(B, device=dev, dtype=torch.int64),
             }
         return self._buf[key]
 
+    def _streams(self, dev):
+        if getattr(self, "_s_real", None) is None:
+            self._s_real = torch.cuda.Stream(device=dev)     # D(real) forward: independent of the generator
+            self._s_gen = torch.cuda.Stream(device=dev)      # the generator's path: D(gen) forward / backward, decoder backward
+        return self._s_real, self._s_gen
+
     def __call__(self, images, captions, max_caption_len: int, train: bool = True, noise_u=None, keep_masks=None,
                  opt_step: bool = True) -> dict:
         """One step.  Returns device tensors: losses [g_loss, d_loss], ids, probs, logits (real, fake, gen).
-        ``noise_u`` [L,B,V] / ``keep_masks`` (3 x [B*R,F]) make the step deterministic for parity runs."""
+        ``noise_u`` [L,B,V] / ``keep_masks`` (3 x [B*R,F]) make the step deterministic for parity runs.
+
+        Independent branches of the step's dependency graph run on side HIP streams behind events:
+          D(real) forward          || encoder + roll-out
+          D(gen) forward           || D(fake) forward
+          G path (D(gen) input-gradient, decoder / encoder-head backward)  ||  D path (backward real + fake, D's Adam)
+        D's weights are not updated before the G path has finished reading them; both paths join before G's Adam."""
         a = self.args
         gen, disc = self.gen, self.disc
         B, L = captions.shape[0], int(max_caption_len)
@@ -74,54 +88,85 @@ class FusedAdvStep:
         g_grads, d_grads = self._grad_lists()
         T = float(gen.decoder.temperature)
         d_train = bool(train)            # dropout active in train mode only (disc.train()/eval(), training.py:215,219)
+        main = torch.cuda.current_stream(dev)
+        overlap = self.overlap
+        s_real, s_gen = self._streams(dev) if overlap else (main, main)
+        km = keep_masks if keep_masks is not None else (None, None, None)
+        seeds = [0 if km[i] is not None else SEEDS.next() for i in range(3)]
+        lg = buf["logits"]
 
-        # ---- features (training.py:144-147)
+        # weight images are refreshed on the main stream before any branch forks
+        self.den.prepare(dparams)
+        self.dec.prepare(gparams)
+        ev_start = main.record_event()
+
+        # ---- D(real) (training.py:162), concurrently with the generator's forward
+        with torch.cuda.stream(s_real):
+            s_real.wait_event(ev_start)
+            if int(getattr(a, "real_as_ids", 1)):
+                real_soft, real_ids = None, captions
+            else:
+                real_soft = self.den.soft_input(torch.nn.functional.one_hot(captions, self.den.V).float())
+                real_ids = None
+            self.den.fwd(dparams, real_soft, real_ids, d_train, km[0], seeds[0], state=buf["st_real"], logits=lg[0])
+            ev_real = s_real.record_event()
+
+        # ---- features (training.py:144-147) and one roll-out (training.py:150)
         if self.cgan:
             feats = gen.encoder.forward_fused(images, train)
         else:
             feats = engine.embedding_fwd(gparams[0], buf["ones"])
-        # ---- one roll-out (training.py:150)
         seed = 0 if noise_u is not None else SEEDS.next()
         probs, ids, dst = self.dec.sample_fwd(gparams, feats, L, T, False, noise_u, seed, state=buf["dec_state"],
                                               out=buf["probs"], ids=buf["ids"])
-        # ---- three discriminator evaluations (training.py:162-164)
-        km = keep_masks if keep_masks is not None else (None, None, None)
-        seeds = [0 if km[i] is not None else SEEDS.next() for i in range(3)]
-        if int(getattr(a, "real_as_ids", 1)):
-            real_soft, real_ids = None, captions
-        else:
-            real_soft = self.den.soft_input(torch.nn.functional.one_hot(captions, self.den.V).float())
-            real_ids = None
-        lg = buf["logits"]
-        self.den.fwd(dparams, real_soft, real_ids, d_train, km[0], seeds[0], state=buf["st_real"], logits=lg[0])
+        ev_probs = main.record_event()
+
+        # ---- D(gen) || D(fake) (training.py:163-164)
+        with torch.cuda.stream(s_gen):
+            s_gen.wait_event(ev_probs)
+            self.den.fwd(dparams, probs, None, d_train, km[2], seeds[2], state=buf["st_gen"], logits=lg[2])
+            ev_gen = s_gen.record_event()
         self.den.fwd(dparams, probs, None, d_train, km[1], seeds[1], state=buf["st_fake"], logits=lg[1])
-        self.den.fwd(dparams, probs, None, d_train, km[2], seeds[2], state=buf["st_gen"], logits=lg[2])
+        main.wait_event(ev_real)
+        main.wait_event(ev_gen)
         losses, lgrads = engine.gan_losses(a.adv_loss_type, lg[0], lg[1], lg[2], want_grads=train)
         out = {"losses": losses, "ids": ids, "probs": probs, "logits": lg}
         if not train:
             return out
+        ev_loss = main.record_event()
 
-        # ---- D backward: d_loss -> D parameters (training.py:168 minus the step)
+        # ---- G path on its stream: g_loss -> D(gen) input grad -> decoder -> encoder head (training.py:169 minus the step)
+        with torch.cuda.stream(s_gen):
+            s_gen.wait_event(ev_loss)
+            if overlap:
+                lgrads["dg_out"].record_stream(s_gen)
+            if a.adv_loss_type == "rsgan":
+                self.gen_arena.grad.zero_()                        # utils.py:48: g_loss has no path to G
+                ev_dgen = s_gen.record_event()
+            else:
+                self.den.bwd(dparams, buf["st_gen"], probs, None, d_train, lgrads["dg_out"], False, True,
+                             ws=buf["disc_ws_gen"], d_inp=buf["d_probs"])
+                ev_dgen = s_gen.record_event()                     # D's weights are free to change from here on
+                self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"],
+                                    grads=g_grads + [buf["d_feat"]])
+                if self.cgan:
+                    gen.encoder.backward_fused(buf["d_feat"])
+                else:   # features = embed(<S>) broadcast: fold d_features into row 1 of the embedding gradient
+                    engine.embedding_bwd(buf["d_feat"], buf["ones"], self.dec.V, d_weight=g_grads[0], zero_first=False)
+            if self.reducer is not None:
+                self.reducer.start(self.gen_arena.grad)
+            ev_g = s_gen.record_event()
+
+        # ---- D path on the main stream: d_loss -> D parameters (training.py:168), then D's clip + Adam
         self.den.bwd(dparams, buf["st_real"], real_soft, real_ids, d_train, lgrads["dd_real"], True, False,
                      grads=d_grads, accumulate=False, ws=buf["disc_ws"])
         self.den.bwd(dparams, buf["st_fake"], probs, None, d_train, lgrads["dd_fake"], True, False,
                      grads=d_grads, accumulate=True, ws=buf["disc_ws"])
         if self.reducer is not None:
-            self.reducer.start(self.disc_arena.grad)           # overlaps with the generator backward below
-        # ---- G backward: g_loss -> D(gen) input grad -> decoder (training.py:169 minus the step)
-        if a.adv_loss_type == "rsgan":
-            self.gen_arena.grad.zero_()                        # utils.py:48: g_loss has no path to G
-        else:
-            self.den.bwd(dparams, buf["st_gen"], probs, None, d_train, lgrads["dg_out"], False, True,
-                         ws=buf["disc_ws"], d_inp=buf["d_probs"])
-            self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"],
-                                grads=g_grads + [buf["d_feat"]])
-            if self.cgan:
-                gen.encoder.backward_fused(buf["d_feat"])
-            else:   # features = embed(<S>) broadcast: fold d_features into row 1 of the embedding gradient
-                engine.embedding_bwd(buf["d_feat"], buf["ones"], self.dec.V, d_weight=g_grads[0], zero_first=False)
+            self.reducer.start(self.disc_arena.grad)
+        main.wait_event(ev_dgen)
+        main.wait_event(ev_g)
         if self.reducer is not None:
-            self.reducer.start(self.gen_arena.grad)
             self.reducer.wait_all()
         if opt_step:
             self.disc_opt.step()
