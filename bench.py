@@ -188,10 +188,12 @@ def main():
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(a.warmup + k)
+    t_enq = time.perf_counter() - t0           # host time to enqueue the K steps (the GPU runs behind it)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
+    log(f"host enqueue {t_enq / a.steps * 1e3:.3f} ms/step of {elapsed / a.steps * 1e3:.3f} ms/step")
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -42,6 +42,7 @@ struct GemmDesc {
   // ---- EPI_BNSTATS: C = result (+bias) and stats[n] += sum_m v, stats[N+n] += sum_m v^2 (f32 atomics)
   float* stats = nullptr;   // [stats_nrep][2N]; block b adds into replica b % stats_nrep (readers sum the replicas)
   int stats_nrep = 1;
+  int dbg = 0;              // phase-ablation knob, honoured only by -DGIC_STAMPS tool builds
 };
 
 // Enqueue on `stream`. Returns GIC_OK or a negative Status (message via gic_last_error()).

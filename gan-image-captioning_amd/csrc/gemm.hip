@@ -34,6 +34,18 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 
+#ifdef GIC_STAMPS
+}  // anon
+__device__ unsigned long long g_stamp[32];
+namespace {
+#define STAMP(i) do { if (tid == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) { \
+  const int o_ = blockIdx.x == 0 ? 0 : 16; g_stamp[o_ + 2 * (i)] = __builtin_amdgcn_s_memtime(); g_stamp[o_ + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define DBG d.dbg      // phase ablation (tools/gemm_stamps.py): 1 = no DMA after the prologue, 2 = no MFMA phase
+#else
+#define STAMP(i) do {} while (0)
+#define DBG 0
+#endif
+
 template <typename T> struct GlobalPtr { typedef const __attribute__((address_space(1))) T* type; };
 
 // PIPE (k-contiguous, vectorised operands only): tiles reach LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPR
@@ -64,6 +76,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  STAMP(0);
   const int wr = w >> 1, wc = w & 1;
   const int lr = lane & 15, lg = lane >> 4;
 
@@ -352,6 +365,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
   if constexpr (PIPE) {
     if (kt0 < kt1) {
       constexpr int NL = CA + CB;                       // LDS-DMA instructions per thread per stage
+      STAMP(1);
       issue(kt0, 0);
       if (kt0 + 1 < kt1) issue(kt0 + 1, 1);
       int buf = 0;
@@ -361,11 +375,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
         if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < kt1) issue(kt + 2, buf >= 1 ? buf - 1 : 2);      // (buf + 2) % 3
-        compute(buf);
+        if (kt == kt0) STAMP(2);
+        if (kt + 2 < kt1 && !(DBG & 1)) issue(kt + 2, buf >= 1 ? buf - 1 : 2);      // (buf + 2) % 3
+        if (!(DBG & 2)) compute(buf);
         buf = buf == 2 ? 0 : buf + 1;
       }
       __syncthreads();                                  // all fragment reads done before the epilogue reuses LDS
+      STAMP(3);
     }
   } else if (kt0 < kt1) {
     int cur = 0;
@@ -423,6 +439,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
         }
       }
       __syncthreads();
+      STAMP(4);
       if constexpr (EPI == EPI_BNSTATS) {
         if (tid < BN) {                                        // column tid: waves (wr=0, wc) and (wr=1, wc)
           const int cwc = tid / (BN / 2), cl = tid % (BN / 2), n = bn0 + tid;
@@ -441,6 +458,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
         const int m = bm0 + ml, n = bn0 + cc * OVE;
         if (m < M && n < N) *(u32x4*)(C + (long)m * d.ldc + n) = *(const u32x4*)(sC + ml * SC + cc * 16);
       }
+      STAMP(5);
       return;
     }
   }
@@ -605,7 +623,11 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
 
-int gemm(const GemmDesc& d, hipStream_t stream) {
+int gemm(const GemmDesc& d0, hipStream_t stream) {
+  GemmDesc d = d0;
+#ifdef GIC_STAMPS
+  { const char* e = getenv("GIC_GEMM_DBG"); if (e) d.dbg = atoi(e); }
+#endif
   GIC_CHECK_ARG(d.A && d.B && d.C, "gemm: null operand");
   GIC_CHECK_ARG(d.M >= 0 && d.N >= 0 && d.K >= 0, "gemm: negative dim");
   if (d.M == 0 || d.N == 0) return GIC_OK;
@@ -632,3 +654,8 @@ int gemm(const GemmDesc& d, hipStream_t stream) {
 }
 
 }  // namespace gic
+#ifdef GIC_STAMPS
+extern "C" int gic_debug_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gic::g_stamp), sizeof(unsigned long long) * 32);
+}
+#endif

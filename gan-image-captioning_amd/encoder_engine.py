@@ -10,6 +10,7 @@ in ONE f32 arena that is zeroed with a single fill and consumed by ONE running-s
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -27,13 +28,12 @@ def _check(status, what):
 
 
 class _ConvStep:
-    __slots__ = ("conv", "bn", "cin", "cout", "k", "stride", "pad", "stats_off", "fold_off", "w", "name")
+    __slots__ = ("conv", "bn", "cin", "cout", "k", "stride", "pad", "stats_off", "w", "name")
 
     def __init__(self, name, conv, bn):
         self.name, self.conv, self.bn = name, conv, bn
         self.cin, self.cout, self.k, self.stride, self.pad = conv.cin, conv.cout, conv.k, conv.stride, conv.pad
         self.stats_off = 0
-        self.fold_off = 0
         self.w = None
 
 
@@ -53,15 +53,16 @@ class TrunkPlan:
         self.steps: List[_ConvStep] = [self.stem]
         for b in self.blocks:
             self.steps += [s for s in (b["c1"], b["c2"], b["c3"], b["ds"]) if s is not None]
-        off = foff = 0
+        off = 0
         for s in self.steps:
-            s.stats_off, s.fold_off = off, foff
+            s.stats_off = off
             off += 2 * s.cout * STATS_REPLICAS
-            foff += 2 * s.cout
-        self.stats_len, self.fold_len = off, foff
+        self.stats_len = off
         self._wkey = None
         self._bufs: Dict[Tuple[int, int], dict] = {}
-        self._folded = None
+        self._graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
+        self._warm: set = set()
+        self.use_graph = not os.environ.get("GIC_NO_GRAPH")
         self.pending_tracked = 0
 
     def sync_counters(self) -> None:
@@ -95,8 +96,7 @@ class TrunkPlan:
         if key in self._bufs:
             return self._bufs[key]
         act = self.act
-        b: dict = {"stats": torch.zeros(self.stats_len, device=dev, dtype=torch.float32),
-                   "folded": torch.zeros(self.fold_len, device=dev, dtype=torch.float32)}
+        b: dict = {"stats": torch.zeros(self.stats_len, device=dev, dtype=torch.float32)}
         b["xin"] = torch.empty(N, S + 6, S + 6, 4, device=dev, dtype=act)
         h = (S + 6 - 7) // 2 + 1
         b["y0"] = torch.empty(N, h, h, 64, device=dev, dtype=act)
@@ -180,13 +180,41 @@ class TrunkPlan:
         lib = L.load()
         self._pack_weights(dev)
         b = self._buffers(N, S, dev)
+        # the caller's image tensor changes from batch to batch: packed into the plan's own NHWC4 buffer outside the graph
+        _check(lib.gic_pack_image(ptr(images.contiguous()), ptr(b["xin"]), self.dtype, N, S, 3, S + 6, stream_ptr()), "gic_pack_image")
+        self._launch_trunk(b, N, S, training)
+        if training:
+            self.pending_tracked += 1          # num_batches_tracked buffers are brought up to date by sync_counters()
+        return b["feat"]
+
+    def _launch_trunk(self, b: dict, N: int, S: int, training: bool) -> None:
+        """Everything behind the packed image runs on the plan's own buffers with fixed arguments: ~105 launches that
+        are replayed as ONE hipGraph (the second call with a given key captures it; GIC_NO_GRAPH=1 keeps eager launches).
+        The key covers every pointer baked into the graph."""
+        if not self.use_graph:
+            return self._run_trunk(b, N, S, training)
+        key = (N, S, bool(training), self._wkey, tuple(t.data_ptr() for s in self.steps for t in (s.bn.weight, s.bn.bias, s.bn.running_mean, s.bn.running_var)))
+        g = self._graphs.get(key)
+        if g is not None:
+            g.replay()
+        elif key not in self._warm:
+            self._warm.add(key)                # first call: eager (lazy code-object loads are not capturable)
+            self._run_trunk(b, N, S, training)
+        else:
+            self._graphs.clear()               # at most one live graph per plan: stale pointers never replay
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._run_trunk(b, N, S, training)
+            self._graphs[key] = g
+            g.replay()
+
+    def _run_trunk(self, b: dict, N: int, S: int, training: bool) -> None:
+        lib = L.load()
         stats = b["stats"] if training else None
-        self._folded = b["folded"] if training else None
         if training:
             b["stats"].zero_()
         rows = b["rows"]
         # stem: 7x7/2 on the zero-bordered NHWC4 image (window [7 x 8 x 4], no bounds checks), bn+relu+maxpool
-        _check(lib.gic_pack_image(ptr(images.contiguous()), ptr(b["xin"]), self.dtype, N, S, 3, S + 6, stream_ptr()), "gic_pack_image")
         self._conv(self.stem, b["xin"], b["y0"], stats, N, S + 6, S + 6, cin=4, kw=8, pad=0)
         h = b["y0"].shape[1]
         a = self._bn_args(self.stem, stats, training)
@@ -218,8 +246,6 @@ class TrunkPlan:
         _check(lib.gic_avgpool(ptr(x), ptr(b["feat"]), self.dtype, N, ho * ho, x.shape[3], stream_ptr()), "gic_avgpool")
         if training:
             _check(lib.gic_bn_running_update(ptr(b["table"]), len(self.steps), stream_ptr()), "gic_bn_running_update")
-            self.pending_tracked += 1          # num_batches_tracked buffers are brought up to date by sync_counters()
-        return b["feat"]
 
     # ---------------------------------------------------------------- measurement helper for bench.py
     def conv_shapes(self, N: int, S: int):
@@ -299,14 +325,13 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None):
     N, S = args.adv_train_batch_size, args.image_size
     stream = torch.cuda.current_stream()
     b = plan._buffers(N, S, encoder.linear.weight.device)
-    plan._folded = None                     # time the convolution kernel alone (no fold launch behind it)
     seen = {}
     for s, xi, yo, H, W, kw, macs in plan.conv_shapes(N, S):
         key = (s.cin, s.cout, s.k, s.stride, H)
         if key not in seen:
             seen[key] = [event_time_ms(lambda: plan._conv(s, xi, yo, b["stats"], N, H, W, **kw), 5, stream), 0, macs, s.name]
         seen[key][1] += 1
-    total_ms = total_flops = 0.0
+    total_ms = total_flops = bound_us = 0.0
     launches = 0
     layers = []
     for key, (ms, count, macs, name) in seen.items():
@@ -315,8 +340,13 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None):
         launches += count
         tf = 2.0 * macs / (ms * 1e-3) / 1e12
         layers.append((tf, name, key, ms, count))
-        print(f"[conv] {name:22s} Cin={key[0]:5d} Cout={key[1]:5d} k={key[2]} s={key[3]} H={key[4]:4d} x{count}: {ms * 1e3:8.1f} us {tf:7.1f} TFLOP/s",
-              file=sys.stderr)
+        Ho = (key[4] + 2 * (key[2] // 2) - key[2]) // key[3] + 1
+        nbytes = 2.0 * (N * key[4] * key[4] * key[0] + N * Ho * Ho * key[1] + key[0] * key[1] * key[2] * key[2])
+        floor_us = max(2.0 * macs / (peak_tflops * 1e12), nbytes / 8e12) * 1e6
+        bound_us += floor_us * count
+        print(f"[conv] {name:22s} Cin={key[0]:5d} Cout={key[1]:5d} k={key[2]} s={key[3]} H={key[4]:4d} x{count}: {ms * 1e3:8.1f} us {tf:7.1f} TFLOP/s "
+              f"{nbytes / (ms * 1e-3) / 1e9:7.0f} GB/s  roofline floor {floor_us:6.1f} us", file=sys.stderr)
+    print(f"[conv] all {launches} launches: {total_ms * 1e3:.1f} us; per-layer max(MFMA, HBM) floor {bound_us:.1f} us", file=sys.stderr)
     layers.sort()
     achieved = total_flops / (total_ms * 1e-3) / 1e12
     fmt = lambda l: {"layer": l[1], "cin": l[2][0], "cout": l[2][1], "k": l[2][2], "stride": l[2][3], "tflops": round(l[0], 1), "us": round(l[3] * 1e3, 1)}
