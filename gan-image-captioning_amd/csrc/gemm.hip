@@ -520,6 +520,255 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// tile8: the bf16 k-contiguous product / implicit-GEMM convolution with EIGHT waves per 128-row tile (2 per SIMD).
+//
+// Measured on MI355X (tools/gemm_stamps.py) the 4-wave kernel above spends ~1500 cycles per 64-deep K tile where the MFMA
+// work is 512: one wave per SIMD serialises its LDS-DMA issue, its fragment reads and its MFMAs, and two tiles in flight do
+// not cover the ~2000-cycle loaded DMA latency.  Here a SIMD holds two waves (one can issue DMA / wait on LDS while the
+// other feeds the matrix pipe), the ring is NS deep (NS-1 tiles in flight) and addressing is cheap:
+//   * tiles reach LDS by `buffer_load_dwordx4 ... lds` behind ONE buffer descriptor per operand: a 32-bit byte offset per
+//     chunk, and an offset beyond the descriptor's extent (conv padding, M/N/K tails, tiles past the end of K) reads as
+//     zero without touching memory -- no 64-bit address math, no branches, no zero page;
+//   * every iteration issues exactly NL DMAs, so the counted s_waitcnt is a constant and the loop body is branch-free.
+// Waves are 4 (M) x 2 (N): a wave owns 32 x BN/2 of the tile.  LDS image, swizzle and C/D layout as in the kernel above.
+template <typename TO, int BN, int EPI, bool CONV, int NS>
+__global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsigned a_bytes, const unsigned b_bytes) {
+  constexpr int BM = 128, BK = 64, NT = 512;
+  constexpr int TM = 2, TN = BN / 32;
+  constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;          // 16-B chunks per thread per tile
+  constexpr int NL = CA + CB;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int OSZ = sizeof(TO), OVE = 16 / OSZ, SC = BN * OSZ + 16;
+  constexpr int EPI_BYTES = BM * SC + 8 * (BN / 2) * 2 * 4;
+  constexpr int SMEM_BYTES = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
+  constexpr unsigned OOB = 0x80000000u;                       // >= any extent this kernel is launched with
+  static_assert(CB >= 1 && SMEM_BYTES <= 160 * 1024, "tile8 LDS budget");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  STAMP(0);
+  const int wr = w >> 1, wc = w & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  const int tiles_m = (d.M + BM - 1) / BM;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int bm0 = (bid % tiles_m) * BM;
+  const int bn0 = (bid / tiles_m) * BN;
+  const int M = d.M, N = d.N, K = d.K;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)d.B, 0, (int)b_bytes, 0x00020000);
+
+  // ---- per-thread chunk coordinates: rows (tid>>3) + 64 i, physical chunk slot tid&7 = logical chunk ^ swizzle(row)
+  const int kc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;           // logical k offset (elements) inside a K tile
+  int a_off[CA], a_hi0[CA], a_wi0[CA];
+  bool a_ok[CA];
+  int cv_r = 0, cv_s = 0, cv_c = 0;
+#pragma unroll
+  for (int i = 0; i < CA; ++i) {
+    const int m = bm0 + (tid >> 3) + i * 64;
+    a_ok[i] = m < M;
+    if constexpr (CONV) {
+      const int mm = a_ok[i] ? m : 0;
+      const int wo = mm % d.cWo, t = mm / d.cWo;
+      const int ho = t % d.cHo, n = t / d.cHo;
+      a_hi0[i] = a_ok[i] ? ho * d.cStride - d.cPad : -(1 << 28);      // rows past M never validate
+      a_wi0[i] = wo * d.cStride - d.cPad;
+      a_off[i] = ((n * d.cH + a_hi0[i]) * d.cW + a_wi0[i]) * d.cCin;
+    } else {
+      a_hi0[i] = a_wi0[i] = 0;
+      a_off[i] = m * (int)d.lda;
+    }
+  }
+  if constexpr (CONV) {
+    cv_c = kc % d.cCin;
+    const int t = kc / d.cCin;
+    cv_s = t % d.cKW;
+    cv_r = t / d.cKW;
+  }
+  int b_off[CB];
+  bool b_ok[CB];
+#pragma unroll
+  for (int i = 0; i < CB; ++i) {
+    const int n = bn0 + (tid >> 3) + i * 64;
+    b_ok[i] = n < N;
+    b_off[i] = n * (int)d.ldb;
+  }
+  const int wbase = (tid & ~63) * 16;
+
+  // one K tile -> ring stage `st`; called once per kt in increasing order (the conv (r,s,c) runs along)
+  auto issue = [&](int kt, int st) {
+    unsigned char* sA = smem + st * STAGE;
+    unsigned char* sB = sA + A_BYTES;
+    const int k = kt * BK + kc;
+    const bool kok = k < K;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      unsigned voff;
+      if constexpr (CONV) {
+        const bool ok = (unsigned)(a_hi0[i] + cv_r) < (unsigned)d.cH & (unsigned)(a_wi0[i] + cv_s) < (unsigned)d.cW & kok;
+        voff = ok ? (unsigned)(a_off[i] + (cv_r * d.cW + cv_s) * d.cCin + cv_c) * 2u : OOB;
+      } else {
+        voff = (a_ok[i] & kok) ? (unsigned)(a_off[i] + k) * 2u : OOB;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(sA + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const unsigned voff = (b_ok[i] & kok) ? (unsigned)(b_off[i] + k) * 2u : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_ptr)(sB + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, 0);
+    }
+    if constexpr (CONV) {
+      cv_c += BK;
+      while (cv_c >= d.cCin) {
+        cv_c -= d.cCin;
+        if (++cv_s == d.cKW) { cv_s = 0; ++cv_r; }
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int st) {
+    const unsigned char* sA = smem + st * STAGE;
+    const unsigned char* sB = sA + A_BYTES;
+    bf16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int row = wr * 32 + t * 16 + lr;
+        fa[ks][t] = *(const bf16x8*)(sA + row * 128 + (((ks * 4 + lg) ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const int row = wc * (BN / 2) + t * 16 + lr;
+        fb[ks][t] = *(const bf16x8*)(sB + row * 128 + (((ks * 4 + lg) ^ ((row >> 1) & 7)) << 4));
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+  };
+
+  // ---- K loop: NS-1 tiles in flight.  Tiles past the end of K are all-OOB DMAs (zero fill, no traffic), so the count
+  // of outstanding DMAs is the same in every iteration.
+  const int nk = (K + BK - 1) / BK;
+  STAMP(1);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s, s);
+  int st = 0, st_fill = NS - 1;
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt has landed once all but this wave's newest (NS-2) tiles are done; the barrier publishes every wave's part
+    // and retires all reads of the stage refilled next (it was computed on in iteration kt-1)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NL) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt == 0) STAMP(2);
+    if (!(DBG & 1)) issue(kt + NS - 1, st_fill);
+    if (!(DBG & 2)) compute(st);
+    st = st == NS - 1 ? 0 : st + 1;
+    st_fill = st_fill == NS - 1 ? 0 : st_fill + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stray zero-fill DMAs must not land in the C tile
+  __syncthreads();
+  STAMP(3);
+
+  // ---- epilogue: C tile through LDS (16-byte row stores), BatchNorm column sums folded across the block
+  TO* __restrict__ C = (TO*)d.C;
+  unsigned char* sC = smem;
+  float* sStat = (float*)(smem + BM * SC);                   // [8 waves][BN/2][2]
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nl = wc * (BN / 2) + j * 16 + lr;
+    const int n = bn0 + nl;
+    const float bias = (d.bias && n < N) ? d.bias[n] : 0.f;
+    float st_s = 0.f, st_q = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ml = wr * 32 + i * 16 + lg * 4 + r;
+        const float v = d.alpha * acc[i][j][r] + bias;
+        *(TO*)(sC + ml * SC + nl * OSZ) = from_f32<TO>(v);
+        if (EPI == EPI_BNSTATS && bm0 + ml < M) { st_s += v; st_q += v * v; }
+      }
+    }
+    if constexpr (EPI == EPI_BNSTATS) {
+      st_s += __shfl_xor(st_s, 16, 64); st_q += __shfl_xor(st_q, 16, 64);
+      st_s += __shfl_xor(st_s, 32, 64); st_q += __shfl_xor(st_q, 32, 64);
+      if (lg == 0) { sStat[(w * (BN / 2) + j * 16 + lr) * 2] = st_s; sStat[(w * (BN / 2) + j * 16 + lr) * 2 + 1] = st_q; }
+    }
+  }
+  __syncthreads();
+  STAMP(4);
+  if constexpr (EPI == EPI_BNSTATS) {
+    if (tid < BN) {                                          // column tid: waves (wr = 0..3, wc)
+      const int cwc = tid / (BN / 2), cl = tid % (BN / 2), n = bn0 + tid;
+      if (n < N) {
+        float s0 = 0.f, q0 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s0 += sStat[((r * 2 + cwc) * (BN / 2) + cl) * 2];
+          q0 += sStat[((r * 2 + cwc) * (BN / 2) + cl) * 2 + 1];
+        }
+        float* stp = d.stats + (long)(blockIdx.x % d.stats_nrep) * 2 * N;
+        atomicAdd(&stp[n], s0);
+        atomicAdd(&stp[N + n], q0);
+      }
+    }
+  }
+  constexpr int CPR = BN / OVE;                              // 16-B chunks per tile row
+  for (int c = tid; c < BM * CPR; c += NT) {
+    const int ml = c / CPR, cc = c % CPR;
+    const int m = bm0 + ml, n = bn0 + cc * OVE;
+    if (m < M && n < N) *(u32x4*)(C + (long)m * d.ldc + n) = *(const u32x4*)(sC + ml * SC + cc * 16);
+  }
+  STAMP(5);
+}
+
+// Launch the 8-wave kernel if the product qualifies (bf16 k-contiguous operands under 2 GiB each, a plain / BatchNorm-sum
+// epilogue that overwrites a 16-byte-aligned C); returns false to fall back to gemm_kernel.
+template <typename TO, int EPI, bool CONV>
+bool try_tile8(const GemmDesc& d, hipStream_t stream) {
+  static const bool off = getenv("GIC_NO_TILE8") != nullptr;
+  constexpr int OVE = 16 / (int)sizeof(TO);
+  if (off || d.accumulate || d.M < 128 || (d.N % OVE) || (d.ldc % OVE) || (((uintptr_t)d.C) & 15)) return false;
+  const long a_elems = CONV ? (long)(d.M / (d.cHo * d.cWo)) * d.cH * d.cW * d.cCin : (long)(d.M - 1) * d.lda + d.K;
+  const long b_elems = (long)(d.N - 1) * d.ldb + d.K;
+  if (a_elems * 2 >= (1l << 31) || b_elems * 2 >= (1l << 31)) return false;
+  const long big_tiles = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
+  static const int big_min = [] { const char* e = getenv("GIC_TILE8_BIG_MIN"); return e ? atoi(e) : 160; }();
+  static const int ns2_tiles = [] { const char* e = getenv("GIC_TILE8_NS2_TILES"); return e ? atoi(e) : 256; }();
+  static const int min_nk = [] { const char* e = getenv("GIC_TILE8_MIN_NK"); return e ? atoi(e) : 1; }();
+  if (cdiv(d.K, 64) < min_nk) return false;
+  const unsigned ab = (unsigned)(a_elems * 2), bb = (unsigned)(b_elems * 2);
+  // deep ring (4 stages, 128 KB: one block per CU) when the grid is about one block per CU; with several blocks per CU a
+  // 2-stage ring (64 KB) lets two blocks share the CU so one block's epilogue runs under the other's K loop
+  if (d.N >= 128 && big_tiles >= big_min) {
+    if (big_tiles > ns2_tiles) hipLaunchKernelGGL((tile8_kernel<TO, 128, EPI, CONV, 2>), dim3((unsigned)big_tiles), dim3(512), 0, stream, d, ab, bb);
+    else hipLaunchKernelGGL((tile8_kernel<TO, 128, EPI, CONV, 4>), dim3((unsigned)big_tiles), dim3(512), 0, stream, d, ab, bb);
+  } else {
+    const long tiles = (long)cdiv(d.M, 128) * cdiv(d.N, 64);
+    if (tiles > ns2_tiles) hipLaunchKernelGGL((tile8_kernel<TO, 64, EPI, CONV, 2>), dim3((unsigned)tiles), dim3(512), 0, stream, d, ab, bb);
+    else hipLaunchKernelGGL((tile8_kernel<TO, 64, EPI, CONV, 4>), dim3((unsigned)tiles), dim3(512), 0, stream, d, ab, bb);
+  }
+  return true;
+}
+
+
 __global__ void zero2d_kernel(float* __restrict__ C, long ldc, int M, int N) {
   const long total = (long)M * N;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
@@ -597,6 +846,9 @@ int pick_layout(const GemmDesc& d, bool vec, hipStream_t stream) {
 
 template <typename TI, typename TO, int EPI>
 int pick_conv(const GemmDesc& d, hipStream_t stream) {
+  if constexpr (sizeof(TI) == 2) {
+    if (try_tile8<TO, EPI, true>(d, stream)) { GIC_CHECK_LAUNCH("conv tile8"); return GIC_OK; }
+  }
   const long big_tiles = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
   if (big_tiles >= big_tile_min() && d.N >= 128) return launch<TI, TO, true, true, 128, 128, true, EPI, true>(d, stream);
   return launch<TI, TO, true, true, 64, 64, true, EPI, true>(d, stream);

@@ -350,7 +350,7 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None):
     layers.sort()
     achieved = total_flops / (total_ms * 1e-3) / 1e12
     fmt = lambda l: {"layer": l[1], "cin": l[2][0], "cout": l[2][1], "k": l[2][2], "stride": l[2][3], "tflops": round(l[0], 1), "us": round(l[3] * 1e3, 1)}
-    return {"kernel": "gemm_kernel<CONV, bf16 16x16x32 MFMA, 128x128|64x64 tile, EPI_BNSTATS>: implicit-GEMM convolution, "
+    return {"kernel": "tile8_kernel<CONV, EPI_BNSTATS>: implicit-GEMM convolution, bf16 16x16x32 MFMA, 128x128|128x64 tile, 8 waves, LDS-DMA ring, "
                       f"{launches} launches/step (every trunk convolution)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(achieved / peak_tflops, 4),
             "traffic": pmc_traffic, "ms_per_launch": round(total_ms / launches, 5), "launches_per_step": launches,
