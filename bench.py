@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--step-impl", default="fused", choices=["fused", "autograd"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=2)
+    p.add_argument("--no-prefetch", action="store_true", help="do not hand the next batch's images to the step (no trunk prefetch)")
     return p.parse_args()
 
 
@@ -174,7 +175,7 @@ def main():
     n_batches, adv_epochs = 50, args.adv_epochs
 
     def step(k):
-        inst.adv_step(images, captions, L, train=True)
+        inst.adv_step(images, captions, L, train=True, next_images=images if (cgan and not a.no_prefetch) else None)
         inst.update_temperature(0 + (k + 1) / n_batches, adv_epochs)      # training.py:183
 
     log(f"instructor ready (cgan={cgan}, dtype={a.dtype}); warm-up {a.warmup} steps")

@@ -38,7 +38,7 @@ class DecoderGrads(C.Structure):
 
 
 class DecoderShadow(C.Structure):
-    _fields_ = [("wcat", c_void_p * MAX_LAYERS), ("bsum", c_void_p * MAX_LAYERS), ("wout", c_void_p)]
+    _fields_ = [("wcat", c_void_p * MAX_LAYERS), ("bsum", c_void_p * MAX_LAYERS), ("wout", c_void_p), ("wcat_t", c_void_p * MAX_LAYERS)]
 
 
 class DecoderState(C.Structure):

@@ -363,7 +363,8 @@ int sample_bwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
   // 3. BPTT
   for (int l = 0; l < NL; ++l) {
     GIC_PROPAGATE(fill_zero(ws->dc[l], (size_t)B * H * sizeof(float), stream));
-    GIC_PROPAGATE(fill_zero(ws->dxh[l] + (long)L * B * c.ldx(l), (size_t)B * c.ldx(l) * sizeof(float), stream));
+    // all L+1 slots at once: slot L is the zero gradient behind the last step, slots < L are split-K accumulators
+    GIC_PROPAGATE(fill_zero(ws->dxh[l], (size_t)(L + 1) * B * c.ldx(l) * sizeof(float), stream));
   }
   for (int t = L - 1; t >= 0; --t) {
     for (int l = NL - 1; l >= 0; --l) {
@@ -379,8 +380,10 @@ int sample_bwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
                          (const float*)(st->c[l] + (long)(t + 1) * B * H), ws->dc[l], dg, B, H);
       GIC_CHECK_LAUNCH("lstm_pointwise_bwd");
       GemmDesc g;   // d[x | h_prev] = d_gates Wcat
-      g.A = dg; g.lda = 4 * H; g.a_kc = 1; g.B = S->wcat[l]; g.ldb = ld; g.b_kc = 0;
-      g.C = ws->dxh[l] + (long)t * B * ld; g.ldc = ld;
+      g.A = dg; g.lda = 4 * H; g.a_kc = 1;
+      if (S->wcat_t[l]) { g.B = S->wcat_t[l]; g.ldb = 4 * H; g.b_kc = 1; }
+      else { g.B = S->wcat[l]; g.ldb = ld; g.b_kc = 0; }
+      g.C = ws->dxh[l] + (long)t * B * ld; g.ldc = ld; g.c_zeroed = 1;
       g.M = B; g.N = (int)ld; g.K = 4 * H; g.in_dtype = c.dt; g.out_dtype = DT_F32;
       GIC_PROPAGATE(gemm(g, stream));
     }
@@ -423,6 +426,19 @@ __global__ void embed_scatter_time_kernel(const float* __restrict__ dxh0, long l
 
 using namespace gic;
 
+// out[c][r] = in[r][c] for a row-major [rows, cols] matrix, 32x32 tiles through LDS (both sides coalesced)
+template <typename TA>
+__global__ void transpose2d_kernel(const TA* __restrict__ in, TA* __restrict__ out, int rows, int cols) {
+  __shared__ TA tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8)
+    if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = in[(long)(r0 + j) * cols + c0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (c0 + j < cols && r0 + tx < rows) out[(long)(c0 + j) * rows + r0 + tx] = tile[tx][j];
+}
+
 extern "C" {
 
 int gic_decoder_prepare(const gic_decoder_dims* dims, const gic_decoder_params* P, const gic_decoder_shadow* S, void* stream_) {
@@ -441,6 +457,14 @@ int gic_decoder_prepare(const gic_decoder_dims* dims, const gic_decoder_params* 
       hipLaunchKernelGGL((build_wcat_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, P->w_ih[l], P->w_hh[l], P->b_ih[l],
                          P->b_hh[l], (bf16_t*)S->wcat[l], S->bsum[l], 4 * c.H, c.din(l), c.H);
     GIC_CHECK_LAUNCH("build_wcat");
+    if (S->wcat_t[l]) {
+      const dim3 tg(cdiv(c.ldx(l), 32), cdiv(4 * c.H, 32));
+      if (c.dt == DT_F32)
+        hipLaunchKernelGGL((transpose2d_kernel<float>), tg, dim3(256), 0, stream, (const float*)S->wcat[l], (float*)S->wcat_t[l], 4 * c.H, (int)c.ldx(l));
+      else
+        hipLaunchKernelGGL((transpose2d_kernel<bf16_t>), tg, dim3(256), 0, stream, (const bf16_t*)S->wcat[l], (bf16_t*)S->wcat_t[l], 4 * c.H, (int)c.ldx(l));
+      GIC_CHECK_LAUNCH("transpose wcat");
+    }
   }
   GIC_CHECK_ARG(P->w_out && S->wout, "decoder_prepare: null w_out");
   if ((const void*)S->wout != (const void*)P->w_out)

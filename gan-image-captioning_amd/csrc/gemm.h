@@ -25,6 +25,7 @@ struct GemmDesc {
   int in_dtype = DT_F32, out_dtype = DT_F32;
   const float* bias = nullptr;   // per output column n (optional)
   int accumulate = 0;            // C += result
+  int c_zeroed = 0;              // caller guarantees C is all zero: a split-K launch skips its own zero fill
   float alpha = 1.f;
   int epi = EPI_PLAIN;
   // ---- EPI_HIGHWAY (discriminator.py:53-58): h = acc+bias; y = sig(h)*relu(h) + (1-sig(h))*x; C = y*keep*keep_scale

@@ -783,7 +783,7 @@ int launch(const GemmDesc& d, hipStream_t stream) {
   // split-K only where the tile grid leaves most of the 256 CUs idle and K is deep enough to share
   int splits = 1;
   // (bf16 compute mode only: the f32 parity mode stays bit-reproducible run to run, atomics reorder the f32 sum)
-  if (EPI == EPI_PLAIN && sizeof(TI) == 2 && sizeof(TO) == 4 && tiles < 24 && nk >= 8) {
+  if (EPI == EPI_PLAIN && sizeof(TI) == 2 && sizeof(TO) == 4 && ((tiles < 24 && nk >= 8) || (tiles <= 64 && nk >= 16))) {
     splits = 256 / tiles;
     if (splits > nk / 2) splits = nk / 2;
     if (splits > 16) splits = 16;
@@ -791,7 +791,7 @@ int launch(const GemmDesc& d, hipStream_t stream) {
   }
   int per = cdiv(nk, splits);
   splits = cdiv(nk, per);
-  if (splits > 1 && !d.accumulate) {
+  if (splits > 1 && !d.accumulate && !d.c_zeroed) {
     const long total = (long)d.M * d.N;
     const int g = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
     hipLaunchKernelGGL(zero2d_kernel, dim3(g), dim3(256), 0, stream, (float*)d.C, d.ldc, d.M, d.N);

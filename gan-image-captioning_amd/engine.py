@@ -185,6 +185,8 @@ class DecoderEngine:
                 "wcat": [torch.empty(4 * self.H, self.ldx(l), device=dev, dtype=self.act) for l in range(self.NL)],
                 "bsum": [torch.empty(4 * self.H, device=dev, dtype=torch.float32) for l in range(self.NL)],
                 "wout": None if self.dt == L.F32 else torch.empty(self.V, self.H, device=dev, dtype=self.act),
+                # bf16 mode: Wcat^T so that the BPTT product d[x|h] = d_gates Wcat runs on k-contiguous operands
+                "wcat_t": None if self.dt == L.F32 else [torch.empty(self.ldx(l), 4 * self.H, device=dev, dtype=self.act) for l in range(self.NL)],
             }
         sh = self._shadow
         s = self._shadow_struct(params)
@@ -200,6 +202,8 @@ class DecoderEngine:
         s.wcat = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in sh["wcat"]])
         s.bsum = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in sh["bsum"]])
         s.wout = ptr(params[1 + 4 * self.NL]) if sh["wout"] is None else ptr(sh["wout"])
+        if sh["wcat_t"] is not None:
+            s.wcat_t = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in sh["wcat_t"]])
         return s
 
     def alloc_state(self, B: int, Lc: int, dev) -> Dict[str, object]:

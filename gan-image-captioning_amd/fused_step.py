@@ -33,6 +33,7 @@ class FusedAdvStep:
         self._gen_grads = None
         self._disc_grads = None
         self.overlap = not os.environ.get("GIC_NO_STREAM_OVERLAP")
+        self.trace = None
 
     # grads of the decoder parameters are views into the generator arena (order = Decoder.param_list())
     def _grad_lists(self):
@@ -61,16 +62,47 @@ class FusedAdvStep:
             }
         return self._buf[key]
 
+    def _mark(self, name: str, stream) -> None:
+        """Phase marker for tools/step_timeline.py (``self.trace`` is a list while tracing, else None)."""
+        if self.trace is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            self.trace.append((name, ev))
+
     def _streams(self, dev):
         if getattr(self, "_s_real", None) is None:
             self._s_real = torch.cuda.Stream(device=dev)     # D(real) forward: independent of the generator
             self._s_gen = torch.cuda.Stream(device=dev)      # the generator's path: D(gen) forward / backward, decoder backward
         return self._s_real, self._s_gen
 
+    # ---- trunk prefetch: the ResNet trunk is frozen (generator.py:21), so the trunk forward of batch k+1 depends on nothing
+    # that step k updates.  It is enqueued on its own stream while step k is in its launch-bound phases (roll-out, D, BPTT).
+    def _prefetch_trunk(self, images, train: bool, after) -> None:
+        if getattr(self, "_s_pre", None) is None:
+            self._s_pre = torch.cuda.Stream(device=images.device)
+        s = self._s_pre
+        with torch.cuda.stream(s):
+            s.wait_event(after)                 # `images` is ready and the previous trunk output has been consumed
+            feats = self.gen.encoder.trunk_features(images, train).clone()
+            done = s.record_event()
+        images.record_stream(s)
+        self._pre = (images, bool(train), feats, done)
+
+    def _trunk_features(self, images, train: bool, main):
+        pre, self._pre = getattr(self, "_pre", None), None
+        if pre is not None:
+            main.wait_event(pre[3])             # also orders a synchronous trunk pass behind an unused prefetch (shared buffers)
+            if pre[0] is images and pre[1] == bool(train):
+                pre[2].record_stream(main)
+                return pre[2]
+        return self.gen.encoder.trunk_features(images, train)
+
     def __call__(self, images, captions, max_caption_len: int, train: bool = True, noise_u=None, keep_masks=None,
-                 opt_step: bool = True) -> dict:
+                 opt_step: bool = True, next_images=None, next_train=None) -> dict:
         """One step.  Returns device tensors: losses [g_loss, d_loss], ids, probs, logits (real, fake, gen).
         ``noise_u`` [L,B,V] / ``keep_masks`` (3 x [B*R,F]) make the step deterministic for parity runs.
+        ``next_images``: the NEXT batch's images (same shape); its trunk forward is enqueued on a side stream under this
+        step and picked up by the next call when it is passed the same tensor (results are identical either way).
 
         Independent branches of the step's dependency graph run on side HIP streams behind events:
           D(real) forward          || encoder + roll-out
@@ -95,14 +127,19 @@ class FusedAdvStep:
         seeds = [0 if km[i] is not None else SEEDS.next() for i in range(3)]
         lg = buf["logits"]
 
-        # weight images are refreshed on the main stream before any branch forks
-        self.den.prepare(dparams)
-        self.dec.prepare(gparams)
+        # compute-dtype weight images are refreshed on the side streams, under the encoder
         ev_start = main.record_event()
+        self._mark("start", main)
+        with torch.cuda.stream(s_gen):
+            s_gen.wait_event(ev_start)
+            self.dec.prepare(gparams)
+            ev_gprep = s_gen.record_event()
 
         # ---- D(real) (training.py:162), concurrently with the generator's forward
         with torch.cuda.stream(s_real):
             s_real.wait_event(ev_start)
+            self.den.prepare(dparams)
+            ev_dprep = s_real.record_event()
             if int(getattr(a, "real_as_ids", 1)):
                 real_soft, real_ids = None, captions
             else:
@@ -110,23 +147,33 @@ class FusedAdvStep:
                 real_ids = None
             self.den.fwd(dparams, real_soft, real_ids, d_train, km[0], seeds[0], state=buf["st_real"], logits=lg[0])
             ev_real = s_real.record_event()
+            self._mark("D(real) fwd done [s_real]", s_real)
 
         # ---- features (training.py:144-147) and one roll-out (training.py:150)
         if self.cgan:
-            feats = gen.encoder.forward_fused(images, train)
+            feats = gen.encoder.forward_fused(images, train, trunk_feats=self._trunk_features(images, train, main))
+            if next_images is not None:
+                self._prefetch_trunk(next_images, train if next_train is None else next_train, main.record_event())
         else:
             feats = engine.embedding_fwd(gparams[0], buf["ones"])
+        self._mark("encoder done", main)
         seed = 0 if noise_u is not None else SEEDS.next()
+        main.wait_event(ev_gprep)
         probs, ids, dst = self.dec.sample_fwd(gparams, feats, L, T, False, noise_u, seed, state=buf["dec_state"],
                                               out=buf["probs"], ids=buf["ids"])
         ev_probs = main.record_event()
+        self._mark("roll-out done", main)
 
         # ---- D(gen) || D(fake) (training.py:163-164)
         with torch.cuda.stream(s_gen):
             s_gen.wait_event(ev_probs)
+            s_gen.wait_event(ev_dprep)
             self.den.fwd(dparams, probs, None, d_train, km[2], seeds[2], state=buf["st_gen"], logits=lg[2])
             ev_gen = s_gen.record_event()
+            self._mark("D(gen) fwd done [s_gen]", s_gen)
+        main.wait_event(ev_dprep)
         self.den.fwd(dparams, probs, None, d_train, km[1], seeds[1], state=buf["st_fake"], logits=lg[1])
+        self._mark("D(fake) fwd done", main)
         main.wait_event(ev_real)
         main.wait_event(ev_gen)
         losses, lgrads = engine.gan_losses(a.adv_loss_type, lg[0], lg[1], lg[2], want_grads=train)
@@ -134,6 +181,7 @@ class FusedAdvStep:
         if not train:
             return out
         ev_loss = main.record_event()
+        self._mark("losses done", main)
 
         # ---- G path on its stream: g_loss -> D(gen) input grad -> decoder -> encoder head (training.py:169 minus the step)
         with torch.cuda.stream(s_gen):
@@ -147,6 +195,7 @@ class FusedAdvStep:
                 self.den.bwd(dparams, buf["st_gen"], probs, None, d_train, lgrads["dg_out"], False, True,
                              ws=buf["disc_ws_gen"], d_inp=buf["d_probs"])
                 ev_dgen = s_gen.record_event()                     # D's weights are free to change from here on
+                self._mark("D(gen) input-grad done [s_gen]", s_gen)
                 self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"],
                                     grads=g_grads + [buf["d_feat"]])
                 if self.cgan:
@@ -156,14 +205,17 @@ class FusedAdvStep:
             if self.reducer is not None:
                 self.reducer.start(self.gen_arena.grad)
             ev_g = s_gen.record_event()
+            self._mark("G path done [s_gen]", s_gen)
 
         # ---- D path on the main stream: d_loss -> D parameters (training.py:168), then D's clip + Adam
+        self.disc_arena.grad.zero_()          # ONE fill; both passes accumulate (instead of a fill per small gradient tensor)
         self.den.bwd(dparams, buf["st_real"], real_soft, real_ids, d_train, lgrads["dd_real"], True, False,
-                     grads=d_grads, accumulate=False, ws=buf["disc_ws"])
+                     grads=d_grads, accumulate=True, ws=buf["disc_ws"])
         self.den.bwd(dparams, buf["st_fake"], probs, None, d_train, lgrads["dd_fake"], True, False,
                      grads=d_grads, accumulate=True, ws=buf["disc_ws"])
         if self.reducer is not None:
             self.reducer.start(self.disc_arena.grad)
+        self._mark("D path done", main)
         main.wait_event(ev_dgen)
         main.wait_event(ev_g)
         if self.reducer is not None:
@@ -171,6 +223,7 @@ class FusedAdvStep:
         if opt_step:
             self.disc_opt.step()
             self.gen_opt.step()
+        self._mark("optimizers done", main)
         return out
 
     def bind_optimizers(self, gen_opt, disc_opt) -> "FusedAdvStep":

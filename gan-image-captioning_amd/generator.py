@@ -207,9 +207,13 @@ class Encoder(nn.Module):
                                     self.bn.running_mean, self.bn.running_var)
 
     # ---- direct (no autograd) forms used by the fused step driver
-    def forward_fused(self, images, training: bool):
+    def trunk_features(self, images, training: bool):
+        """The frozen trunk alone (generator.py:20-22): pooled features in the compute dtype, in the plan's own buffer."""
+        return self.resnet(images, _compute_dtype(self.args), training)
+
+    def forward_fused(self, images, training: bool, trunk_feats=None):
         dt = _compute_dtype(self.args)
-        feats = self.resnet(images, dt, training)
+        feats = trunk_feats if trunk_feats is not None else self.resnet(images, dt, training)
         out, self._saved = encoder_head_fwd(dt, feats, self.linear.weight.detach(), self.linear.bias.detach(),
                                             self.bn.weight.detach(), self.bn.bias.detach(), self.bn.running_mean,
                                             self.bn.running_var, training, self.bn.momentum, self.bn.eps)

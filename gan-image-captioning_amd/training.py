@@ -56,6 +56,23 @@ class _ScalarWriter:
             self._fh.flush()
 
 
+def _lookahead(loader, device):
+    """(batch on device, next batch on device or None): the adversarial loop hands the next images to the step so that
+    their trunk forward overlaps this step (FusedAdvStep._prefetch_trunk)."""
+    def to_dev(b):
+        return (b[0].to(device), b[1].to(device), b[2], b[3])
+    it = iter(loader)
+    try:
+        cur = to_dev(next(it))
+    except StopIteration:
+        return
+    for b in it:
+        nxt = to_dev(b)
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
 class GANInstructor:
     def __init__(self, args, train_dataset, dev_dataset):
         self.args = args
@@ -167,11 +184,12 @@ class GANInstructor:
         return total_loss / epochs if epochs != 0 else 0
 
     # ------------------------------------------------------------------ adversarial step (training.py:136-183)
-    def adv_step(self, images, captions, max_caption_len, train=True, noise_u=None, keep_masks=None):
-        """One minibatch.  Returns (g_loss, d_loss) as a 2-element device tensor (one host sync to read)."""
+    def adv_step(self, images, captions, max_caption_len, train=True, noise_u=None, keep_masks=None, next_images=None):
+        """One minibatch.  Returns (g_loss, d_loss) as a 2-element device tensor (one host sync to read).
+        ``next_images`` (optional): the next batch's images on the device, for the trunk prefetch of the fused step."""
         impl = getattr(self.args, "step_impl", "fused")
         if impl == "fused":
-            return self.fused(images, captions, max_caption_len, train, noise_u, keep_masks)["losses"]
+            return self.fused(images, captions, max_caption_len, train, noise_u, keep_masks, next_images=next_images)["losses"]
         return self._adv_step_autograd(images, captions, max_caption_len, train, noise_u, keep_masks)
 
     def _adv_step_autograd(self, images, captions, max_caption_len, train, noise_u=None, keep_masks=None):
@@ -211,10 +229,10 @@ class GANInstructor:
         float_epoch = 0.0
         gen_loss, disc_loss = [], []
         with tqdm(total=total, disable=self.dist.rank != 0) as progress:
-            for images, captions, lengths, max_caption_len in loader:
+            for (images, captions, lengths, max_caption_len), nxt in _lookahead(loader, self.args.device):
                 float_epoch += 1
-                images, captions = images.to(self.args.device), captions.to(self.args.device)
-                losses = self.adv_step(images, captions, max_caption_len, train=(what == "train"))
+                losses = self.adv_step(images, captions, max_caption_len, train=(what == "train"),
+                                       next_images=nxt[0] if nxt is not None and nxt[0].shape == images.shape else None)
                 g_val, d_val = losses.tolist()                                   # the step's single host sync
                 self.writer.add_scalar("Discriminator_train_loss" if what == "train" else "Discriminator_val_loss", d_val, self.disc_steps)
                 self.disc_steps += 1

@@ -96,6 +96,8 @@ typedef struct gic_decoder_shadow {
   void* wcat[GIC_MAX_LAYERS];            /* act [4H, Din_k+H] = [w_ih | w_hh] */
   float* bsum[GIC_MAX_LAYERS];           /* [4H] = b_ih + b_hh */
   void* wout;                            /* act [V,H] (may alias params.w_out in f32 mode) */
+  void* wcat_t[GIC_MAX_LAYERS];          /* act [Din_k+H, 4H] = Wcat^T, the k-contiguous operand of the BPTT input-gradient
+                                            product; NULL: that product reads Wcat transposed instead */
 } gic_decoder_shadow;
 
 /* Saved-for-backward state + scratch of one sample() call (caller-owned). Din_0=E, Din_k=H. */

@@ -219,3 +219,44 @@ def test_conditional_step_f32_matches_oracle(dev, impl):
     for n in ("encoder.linear.weight", "encoder.bn.weight", "encoder.bn.bias", "decoder.lstm.weight_ih_l0", "decoder.linear.weight"):
         err = rel_l2(got[n], want[n])
         assert err < 2e-2, f"{n}: rel L2 {err}"
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_trunk_prefetch_is_equivalent(dev, dtype):
+    """The next batch's trunk forward enqueued under the current step (FusedAdvStep next_images=) changes nothing:
+    three steps on three different image batches, with and without the look-ahead, incl. a mispredicted look-ahead."""
+    from gan_image_captioning_amd.args import default_args
+    from gan_image_captioning_amd.training import GANInstructor
+    kw = dict(vocab_size=64, gen_embed_dim=32, gen_hidden_dim=64, conditional_gan=1, encoder_arch="resnet18", compute_dtype=dtype,
+              device="cuda", log_file=None, model_dir=None, save_dir=None, image_size=32)
+    a = GANInstructor(default_args(**kw), None, None)
+    b = GANInstructor(default_args(**kw), None, None)
+    b.gen.load_state_dict(a.gen.state_dict())
+    b.disc.load_state_dict(a.disc.state_dict())
+    g = torch.Generator().manual_seed(5)
+    B, L, V = 8, 6, 64
+    imgs = [torch.randn(B, 3, 32, 32, generator=g).to(dev) for _ in range(3)]
+    caps = O.make_captions(B, L, V, g).to(dev)
+    us, masks = O.make_noise(B, L, V, 900, 64, g)
+    u = torch.stack(us).to(dev)
+    km = [k.to(dev) for k in masks]
+    stray = torch.randn(B, 3, 32, 32, generator=g).to(dev)
+    outs = {}
+    for name, inst, nxt in (("plain", a, [None, None, None]), ("prefetch", b, [imgs[1], stray, None])):   # step 1 mispredicts
+        inst.gen.train(); inst.disc.train()
+        rows = []
+        for k in range(3):
+            o = inst.fused(imgs[k], caps, L, True, u, km, next_images=nxt[k])
+            rows.append((o["losses"].clone(), o["ids"].clone()))
+        torch.cuda.synchronize()
+        outs[name] = (rows, inst.gen_arena.flat.clone(), inst.disc_arena.flat.clone(),
+                      int(inst.gen.encoder.resnet.state_dict()["1.num_batches_tracked"]))
+    tol = dict(rtol=2e-4, atol=1e-6) if dtype == "fp32" else dict(rtol=3e-2, atol=1e-4)
+    for (l0, i0), (l1, i1) in zip(outs["plain"][0], outs["prefetch"][0]):
+        if dtype == "fp32":
+            assert torch.equal(i0, i1)
+        torch.testing.assert_close(l0, l1, **tol)
+    # trunk BatchNorm running statistics saw the same three batches in the same order (+ the stray one, once)
+    assert outs["plain"][3] == 3 and outs["prefetch"][3] == 4
+    if dtype == "fp32":
+        torch.testing.assert_close(outs["plain"][2], outs["prefetch"][2], rtol=1e-3, atol=1e-5)
