@@ -79,12 +79,15 @@ class FusedAdvStep:
     # that step k updates.  It is enqueued on its own stream while step k is in its launch-bound phases (roll-out, D, BPTT).
     def _prefetch_trunk(self, images, train: bool, after) -> None:
         if getattr(self, "_s_pre", None) is None:
-            self._s_pre = torch.cuda.Stream(device=images.device)
+            prio = int(os.environ.get("GIC_PREFETCH_PRIORITY", "0"))
+            self._s_pre = torch.cuda.Stream(device=images.device, priority=prio)
         s = self._s_pre
         with torch.cuda.stream(s):
             s.wait_event(after)                 # `images` is ready and the previous trunk output has been consumed
+            self._mark("trunk prefetch start [s_pre]", s)
             feats = self.gen.encoder.trunk_features(images, train).clone()
             done = s.record_event()
+            self._mark("trunk prefetch done [s_pre]", s)
         images.record_stream(s)
         self._pre = (images, bool(train), feats, done)
 
@@ -151,9 +154,10 @@ class FusedAdvStep:
 
         # ---- features (training.py:144-147) and one roll-out (training.py:150)
         if self.cgan:
-            feats = gen.encoder.forward_fused(images, train, trunk_feats=self._trunk_features(images, train, main))
-            if next_images is not None:
-                self._prefetch_trunk(next_images, train if next_train is None else next_train, main.record_event())
+            trunk_feats = self._trunk_features(images, train, main)
+            if next_images is not None:          # the prefetched output is a private copy: the next trunk pass may start now
+                self._prefetch_trunk(next_images, train if next_train is None else next_train, ev_start)
+            feats = gen.encoder.forward_fused(images, train, trunk_feats=trunk_feats)
         else:
             feats = engine.embedding_fwd(gparams[0], buf["ones"])
         self._mark("encoder done", main)
