@@ -103,6 +103,8 @@ _SIGNATURES = {
     "gic_disc_prepare": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), c_void_p]),
     "gic_disc_fwd": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), _P(DiscState), c_void_p, C.c_int64, c_void_p,
                                C.c_int, c_void_p, C.c_uint64, c_void_p, c_void_p]),
+    "gic_disc_fwd_redrop": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), _P(DiscState), _P(DiscState), C.c_int, c_void_p,
+                            C.c_uint64, c_void_p, c_void_p]),
     "gic_disc_bwd": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), _P(DiscState), _P(DiscBwdWs), c_void_p,
                                C.c_int64, c_void_p, C.c_int, c_void_p, _P(DiscGrads), C.c_int, c_void_p, C.c_int64, c_void_p]),
     "gic_pack_image": (C.c_int, [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),

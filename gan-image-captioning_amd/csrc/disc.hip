@@ -316,6 +316,19 @@ inline int grid1d(long total, int cap = 2048) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+// feature2out + out2logits on st->ydrop
+int disc_head_fwd(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S, const gic_disc_state* st, float* logits,
+                  hipStream_t stream) {
+  GemmDesc g;
+  g.A = st->ydrop; g.lda = c.Fp; g.B = S->f2o_w; g.ldb = c.Fp; g.C = st->feat; g.ldc = kOutDim;
+  g.M = (int)c.rowsBR; g.N = kOutDim; g.K = c.Fp; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.bias = P->f2o_b;
+  GIC_PROPAGATE(gemm(g, stream));
+  hipLaunchKernelGGL(disc_out_fwd_kernel, dim3(cdiv(c.rowsBR, 256)), dim3(256), 0, stream, (const float*)st->feat, P->o2l_w, P->o2l_b,
+                     logits, c.rowsBR);
+  GIC_CHECK_LAUNCH("disc_out_fwd");
+  return GIC_OK;
+}
+
 template <typename TA>
 int disc_fwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S, const gic_disc_state* st,
                const void* inp_soft, long ld_inp, const int64_t* inp_ids, int train, const uint8_t* keep_mask,
@@ -355,17 +368,54 @@ int disc_fwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
     }
     GIC_PROPAGATE(gemm(g, stream));
   }
-  // 4. feature2out, out2logits
-  {
-    GemmDesc g;
-    g.A = st->ydrop; g.lda = c.Fp; g.B = S->f2o_w; g.ldb = c.Fp; g.C = st->feat; g.ldc = kOutDim;
-    g.M = (int)c.rowsBR; g.N = kOutDim; g.K = c.Fp; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.bias = P->f2o_b;
-    GIC_PROPAGATE(gemm(g, stream));
+  return disc_head_fwd(c, P, S, st, logits, stream);
+}
+
+// The same highway output under ANOTHER dropout draw, from the saved pre-activation h and carry x (no GEMM):
+// y = sig(h) relu(h) + (1 - sig(h)) x, exactly the EPI_HIGHWAY epilogue incl. its Philox indexing (4 rows per draw).
+template <typename TA>
+__global__ void disc_highway_redrop_kernel(const float* __restrict__ hpre, const TA* __restrict__ pooled,
+                                           const uint8_t* __restrict__ mask, int train, uint64_t seed, float drop_p,
+                                           float keep_scale, TA* __restrict__ ydrop, uint8_t* __restrict__ keep_out,
+                                           long rows, int F, int Fp) {
+  const long groups = (rows + 3) / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups * F; i += (long)gridDim.x * blockDim.x) {
+    const long m4 = i / F;
+    const int n = (int)(i % F);
+    float keep4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (train && !mask) {
+      uint32_t r0, r1, r2, r3;
+      Philox::gen4(seed, 0x44495343ull, (uint64_t)m4 * (uint64_t)F + (uint64_t)n, r0, r1, r2, r3);
+      keep4[0] = Philox::u01(r0) >= drop_p ? 1.f : 0.f;
+      keep4[1] = Philox::u01(r1) >= drop_p ? 1.f : 0.f;
+      keep4[2] = Philox::u01(r2) >= drop_p ? 1.f : 0.f;
+      keep4[3] = Philox::u01(r3) >= drop_p ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long m = m4 * 4 + r;
+      if (m >= rows) break;
+      const float h = hpre[m * Fp + n];
+      const float x = to_f32<TA>(pooled[m * Fp + n]);
+      const float sg = 1.f / (1.f + expf(-h));
+      const float y = sg * fmaxf(h, 0.f) + (1.f - sg) * x;
+      float keep = keep4[r];
+      if (train && mask) keep = (float)mask[m * F + n];
+      if (keep_out) keep_out[m * Fp + n] = (uint8_t)keep;
+      ydrop[m * Fp + n] = from_f32<TA>(y * keep * keep_scale);
+    }
   }
-  hipLaunchKernelGGL(disc_out_fwd_kernel, dim3(cdiv(c.rowsBR, 256)), dim3(256), 0, stream, (const float*)st->feat, P->o2l_w, P->o2l_b,
-                     logits, c.rowsBR);
-  GIC_CHECK_LAUNCH("disc_out_fwd");
-  return GIC_OK;
+}
+
+template <typename TA>
+int disc_fwd_redrop_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S, const gic_disc_state* src,
+                      const gic_disc_state* dst, int train, const uint8_t* keep_mask, uint64_t seed, float* logits, hipStream_t stream) {
+  const long groups = (c.rowsBR + 3) / 4;
+  hipLaunchKernelGGL((disc_highway_redrop_kernel<TA>), dim3(grid1d(groups * c.F)), dim3(256), 0, stream, (const float*)src->hpre,
+                     (const TA*)src->pooled, keep_mask, train, seed, 0.2f, train ? 1.f / (1.f - 0.2f) : 1.f, (TA*)dst->ydrop,
+                     train ? dst->keep : nullptr, c.rowsBR, c.F, c.Fp);
+  GIC_CHECK_LAUNCH("disc_highway_redrop");
+  return disc_head_fwd(c, P, S, dst, logits, stream);
 }
 
 template <typename TA>
@@ -498,6 +548,18 @@ int gic_disc_fwd(const gic_disc_dims* dims, const gic_disc_params* P, const gic_
   if (c.dt == DT_F32)
     return disc_fwd_t<float>(c, P, S, st, inp_soft, ld_inp, inp_ids, train, keep_mask, seed, logits, (hipStream_t)stream);
   return disc_fwd_t<bf16_t>(c, P, S, st, inp_soft, ld_inp, inp_ids, train, keep_mask, seed, logits, (hipStream_t)stream);
+}
+
+int gic_disc_fwd_redrop(const gic_disc_dims* dims, const gic_disc_params* P, const gic_disc_shadow* S, const gic_disc_state* src,
+                        const gic_disc_state* dst, int train, const uint8_t* keep_mask, uint64_t seed, float* logits, void* stream) {
+  DCtx c;
+  GIC_PROPAGATE(make_ctx(dims, P, nullptr, c));
+  GIC_CHECK_ARG(P && S && src && dst && logits, "disc_fwd_redrop: null argument");
+  GIC_CHECK_ARG(src->pooled && src->hpre && dst->ydrop && dst->feat && (!train || dst->keep), "disc_fwd_redrop: null state buffer");
+  GIC_CHECK_ARG(P->f2o_b && P->o2l_w && P->o2l_b && S->f2o_w, "disc_fwd_redrop: null parameter");
+  if (c.dt == DT_F32)
+    return disc_fwd_redrop_t<float>(c, P, S, src, dst, train, keep_mask, seed, logits, (hipStream_t)stream);
+  return disc_fwd_redrop_t<bf16_t>(c, P, S, src, dst, train, keep_mask, seed, logits, (hipStream_t)stream);
 }
 
 int gic_disc_bwd(const gic_disc_dims* dims, const gic_disc_params* P, const gic_disc_shadow* S, const gic_disc_state* st,

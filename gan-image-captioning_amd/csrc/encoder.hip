@@ -220,31 +220,47 @@ __global__ void bn_running_update_kernel(const gic_bn_running_desc* __restrict__
   }
 }
 
-// ---- BatchNorm1d over the batch axis of x [B,E]; one wave per feature column group
+// ---- BatchNorm1d over the batch axis of x [B,E]: a block owns 16 feature columns, its 16 row groups stride the batch
+// (16 loads in flight per column instead of one dependent chain) and fold through LDS
+__device__ __forceinline__ float bn1d_colsum(float v, float (*red)[17], int r, int c) {
+  red[r][c] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t += red[i][c];
+  __syncthreads();
+  return t;
+}
+
 __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ run_mean,
                                                         float* __restrict__ run_var, int training, float momentum, float eps,
                                                         float* __restrict__ y, float* __restrict__ xhat, float* __restrict__ invstd,
                                                         int B, int E) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  float mean, var;
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + c;
+  const bool live = e < E;
+  float mean = 0.f, var = 1.f;
   if (training) {
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += x[(long)b * E + e];
-    mean = s / (float)B;
+    if (live) for (int b = r; b < B; b += 16) s += x[(long)b * E + e];
+    mean = bn1d_colsum(s, red, r, c) / (float)B;
     float q = 0.f;
-    for (int b = 0; b < B; ++b) { const float d = x[(long)b * E + e] - mean; q += d * d; }
-    var = q / (float)B;
-    run_mean[e] = (1.f - momentum) * run_mean[e] + momentum * mean;
-    run_var[e] = (1.f - momentum) * run_var[e] + momentum * var * (B > 1 ? (float)B / (float)(B - 1) : 1.f);
-  } else {
+    if (live) for (int b = r; b < B; b += 16) { const float d = x[(long)b * E + e] - mean; q += d * d; }
+    var = bn1d_colsum(q, red, r, c) / (float)B;
+    if (live && r == 0) {
+      run_mean[e] = (1.f - momentum) * run_mean[e] + momentum * mean;
+      run_var[e] = (1.f - momentum) * run_var[e] + momentum * var * (B > 1 ? (float)B / (float)(B - 1) : 1.f);
+    }
+  } else if (live) {
     mean = run_mean[e]; var = run_var[e];
   }
+  if (!live) return;
   const float is = rsqrtf(var + eps);
-  invstd[e] = is;
+  if (r == 0) invstd[e] = is;
   const float g = gamma[e], bt = beta[e];
-  for (int b = 0; b < B; ++b) {
+  for (int b = r; b < B; b += 16) {
     const float xh = (x[(long)b * E + e] - mean) * is;
     xhat[(long)b * E + e] = xh;
     y[(long)b * E + e] = xh * g + bt;
@@ -255,15 +271,19 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                         int training, float* __restrict__ dx, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, int B, int E) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + c;
+  const bool live = e < E;
   float sg = 0.f, sb = 0.f;
-  for (int b = 0; b < B; ++b) { const float d = dy[(long)b * E + e]; sg += d * xhat[(long)b * E + e]; sb += d; }
-  dgamma[e] = sg;
-  dbeta[e] = sb;
+  if (live) for (int b = r; b < B; b += 16) { const float d = dy[(long)b * E + e]; sg += d * xhat[(long)b * E + e]; sb += d; }
+  sg = bn1d_colsum(sg, red, r, c);
+  sb = bn1d_colsum(sb, red, r, c);
+  if (!live) return;
+  if (r == 0) { dgamma[e] = sg; dbeta[e] = sb; }
   const float k = gamma[e] * invstd[e];
   const float invB = 1.f / (float)B;
-  for (int b = 0; b < B; ++b) {
+  for (int b = r; b < B; b += 16) {
     const float d = dy[(long)b * E + e];
     dx[(long)b * E + e] = training ? k * (d - invB * (sb + xhat[(long)b * E + e] * sg)) : k * d;
   }
@@ -405,7 +425,7 @@ int gic_bn_running_update(const gic_bn_running_desc* table_dev, int nlayers, voi
 int gic_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int training,
                  float momentum, float eps, float* y, float* xhat, float* invstd, int B, int E, void* stream) {
   GIC_CHECK_ARG(x && gamma && beta && running_mean && running_var && y && xhat && invstd && B > 0 && E > 0, "bn1d_fwd: bad argument");
-  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(E, 256)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, running_mean, running_var,
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(E, 16)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, running_mean, running_var,
                      training, momentum, eps, y, xhat, invstd, B, E);
   GIC_CHECK_LAUNCH("bn1d_fwd");
   return GIC_OK;
@@ -414,7 +434,7 @@ int gic_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* r
 int gic_bn1d_bwd(const float* dy, const float* xhat, const float* invstd, const float* gamma, int training, float* dx, float* dgamma,
                  float* dbeta, int B, int E, void* stream) {
   GIC_CHECK_ARG(dy && xhat && invstd && gamma && dx && dgamma && dbeta && B > 0 && E > 0, "bn1d_bwd: bad argument");
-  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(E, 256)), dim3(256), 0, (hipStream_t)stream, dy, xhat, invstd, gamma, training, dx,
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(E, 16)), dim3(256), 0, (hipStream_t)stream, dy, xhat, invstd, gamma, training, dx,
                      dgamma, dbeta, B, E);
   GIC_CHECK_LAUNCH("bn1d_bwd");
   return GIC_OK;

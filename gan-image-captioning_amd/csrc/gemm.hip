@@ -783,10 +783,16 @@ int launch(const GemmDesc& d, hipStream_t stream) {
   // split-K only where the tile grid leaves most of the 256 CUs idle and K is deep enough to share
   int splits = 1;
   // (bf16 compute mode only: the f32 parity mode stays bit-reproducible run to run, atomics reorder the f32 sum)
-  if (EPI == EPI_PLAIN && sizeof(TI) == 2 && sizeof(TO) == 4 && ((tiles < 24 && nk >= 8) || (tiles <= 64 && nk >= 16))) {
-    splits = 256 / tiles;
-    if (splits > nk / 2) splits = nk / 2;
-    if (splits > 16) splits = 16;
+  if (EPI == EPI_PLAIN && sizeof(TI) == 2 && sizeof(TO) == 4) {
+    if (tiles < 24 && nk >= 8) {                 // skinny recurrent / head products: fill the chip
+      splits = 256 / tiles;
+      if (splits > nk / 2) splits = nk / 2;
+      if (splits > 16) splits = 16;
+    } else if (tiles <= 192 && nk >= 32) {       // deep-K gradients over few tiles (K = B*L or V): ~2 blocks per CU
+      splits = 512 / tiles;
+      if (splits > nk / 8) splits = nk / 8;
+      if (splits > 16) splits = 16;
+    }
     if (splits < 1) splits = 1;
   }
   int per = cdiv(nk, splits);

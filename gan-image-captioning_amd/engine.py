@@ -440,6 +440,35 @@ class DiscEngine:
             stream_ptr()), "gic_disc_fwd")
         return logits, st
 
+    def shared_state(self, src: dict, B: int, Lc: int, dev) -> dict:
+        """State of a second forward on the same input: its own dropout / head buffers, the rest aliases ``src``."""
+        st = dict(src)
+        own = self.alloc_state(B, Lc, dev)
+        for k in ("keep", "ydrop", "feat"):
+            st[k] = own[k]
+        return st
+
+    def fwd_redrop(self, params, src_state: dict, dst_state: dict, train: bool, keep_mask: Optional[torch.Tensor] = None,
+                   seed: int = 0, logits=None):
+        """gic_disc_fwd_redrop: D on the same input as the forward that filled ``src_state``, under another dropout draw."""
+        self.check_params(params)
+        MR = src_state["pooled"].shape[0]
+        dev = src_state["pooled"].device
+        if keep_mask is not None:
+            require_gpu(keep_mask)
+            if tuple(keep_mask.shape) != (MR, self.F):
+                raise ValueError(f"keep_mask must be [B*R={MR}, F={self.F}]")
+            keep_mask = keep_mask.to(torch.uint8).contiguous()
+        self.prepare(params)
+        logits = logits if logits is not None else torch.empty(MR, device=dev, dtype=torch.float32)
+        B = MR // self.R
+        d = self.dims(B, src_state["emb"].shape[0] // B)
+        L.check(L.load().gic_disc_fwd_redrop(
+            C.byref(d), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(src_state)),
+            C.byref(self._state_struct(dst_state)), int(bool(train)), ptr(keep_mask), int(seed) & (2 ** 64 - 1), ptr(logits),
+            stream_ptr()), "gic_disc_fwd_redrop")
+        return logits, dst_state
+
     def bwd(self, params, st, inp_soft, inp_ids, train: bool, d_logits: torch.Tensor, want_param_grads: bool,
             want_input_grad: bool, grads=None, accumulate: bool = False, ws=None, d_inp=None):
         src = inp_soft if inp_soft is not None else inp_ids

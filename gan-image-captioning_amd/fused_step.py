@@ -55,11 +55,13 @@ class FusedAdvStep:
                 "ids": torch.empty(B, L, device=dev, dtype=torch.int64),
                 "d_feat": torch.empty(B, dec.E, device=dev, dtype=torch.float32),
                 "d_probs": torch.empty(B, L, dec.V, device=dev, dtype=dec.act),
-                "st_real": den.alloc_state(B, L, dev), "st_fake": den.alloc_state(B, L, dev), "st_gen": den.alloc_state(B, L, dev),
+                "st_real": den.alloc_state(B, L, dev), "st_fake": den.alloc_state(B, L, dev),
                 "disc_ws": den.alloc_bwd_ws(B, L, dev), "disc_ws_gen": den.alloc_bwd_ws(B, L, dev),
                 "logits": torch.empty(3, B * den.R, device=dev, dtype=torch.float32),
                 "ones": torch.ones(B, device=dev, dtype=torch.int64),
             }
+            # D(gen) sees the same input as D(fake) (training.py:163-164): it shares everything up to the dropout draw
+            self._buf[key]["st_gen"] = den.shared_state(self._buf[key]["st_fake"], B, L, dev)
         return self._buf[key]
 
     def _mark(self, name: str, stream) -> None:
@@ -108,8 +110,7 @@ class FusedAdvStep:
         step and picked up by the next call when it is passed the same tensor (results are identical either way).
 
         Independent branches of the step's dependency graph run on side HIP streams behind events:
-          D(real) forward          || encoder + roll-out
-          D(gen) forward           || D(fake) forward
+          D(real) forward          || encoder head + roll-out         (and the NEXT batch's trunk forward under all of it)
           G path (D(gen) input-gradient, decoder / encoder-head backward)  ||  D path (backward real + fake, D's Adam)
         D's weights are not updated before the G path has finished reading them; both paths join before G's Adam."""
         a = self.args
@@ -168,18 +169,12 @@ class FusedAdvStep:
         ev_probs = main.record_event()
         self._mark("roll-out done", main)
 
-        # ---- D(gen) || D(fake) (training.py:163-164)
-        with torch.cuda.stream(s_gen):
-            s_gen.wait_event(ev_probs)
-            s_gen.wait_event(ev_dprep)
-            self.den.fwd(dparams, probs, None, d_train, km[2], seeds[2], state=buf["st_gen"], logits=lg[2])
-            ev_gen = s_gen.record_event()
-            self._mark("D(gen) fwd done [s_gen]", s_gen)
+        # ---- D(fake), D(gen) (training.py:163-164): one pass up to the highway layer, two dropout draws + heads
         main.wait_event(ev_dprep)
         self.den.fwd(dparams, probs, None, d_train, km[1], seeds[1], state=buf["st_fake"], logits=lg[1])
-        self._mark("D(fake) fwd done", main)
+        self.den.fwd_redrop(dparams, buf["st_fake"], buf["st_gen"], d_train, km[2], seeds[2], logits=lg[2])
+        self._mark("D(fake), D(gen) fwd done", main)
         main.wait_event(ev_real)
-        main.wait_event(ev_gen)
         losses, lgrads = engine.gan_losses(a.adv_loss_type, lg[0], lg[1], lg[2], want_grads=train)
         out = {"losses": losses, "ids": ids, "probs": probs, "logits": lg}
         if not train:

@@ -201,6 +201,14 @@ int gic_disc_fwd(const gic_disc_dims* dims, const gic_disc_params* params, const
                  const gic_disc_state* state, const void* inp_soft, int64_t ld_inp, const int64_t* inp_ids,
                  int train, const uint8_t* keep_mask, uint64_t seed, float* logits, void* stream);
 
+/* A second forward on the SAME input as the pass that filled `src` (training.py:163-164 run D twice on gen_captions: only
+ * the dropout draw differs): reuses src's pooled features and highway pre-activation, applies a fresh dropout mask
+ * (keep_mask or Philox(seed)) and the feature2out / out2logits head.  Writes dst->keep, dst->ydrop, dst->feat and logits; for
+ * the backward pass of this forward, dst->emb / pooled / argmax / hpre must alias src's buffers. */
+int gic_disc_fwd_redrop(const gic_disc_dims* dims, const gic_disc_params* params, const gic_disc_shadow* shadow,
+                        const gic_disc_state* src, const gic_disc_state* dst, int train, const uint8_t* keep_mask,
+                        uint64_t seed, float* logits, void* stream);
+
 /* d_logits f32 [B*R].  grads may be NULL (no parameter gradients wanted: the generator's path,
  * training.py:169).  d_inp: act [B*L, V] (row stride ld_dinp) or NULL. */
 int gic_disc_bwd(const gic_disc_dims* dims, const gic_disc_params* params, const gic_disc_shadow* shadow,

@@ -295,6 +295,48 @@ def test_disc_philox_dropout(E, dev):
     close(l1, want, rtol=1e-4, atol_scale=1e-5, what="philox-dropout logits")
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+def test_disc_second_forward_shares_the_first(E, dev, dt):
+    """training.py:163-164 evaluate D twice on gen_captions; gic_disc_fwd_redrop reuses the first pass up to the highway
+    pre-activation.  Same mask / same seed => the very logits of a full second forward; and its backward (on the aliased
+    state) equals the backward of that full forward."""
+    g = Golden("cfg1")
+    _, dp = initial_params(g)
+    m = g.meta
+    eng = _disc(E, m, dt)
+    params = disc_params(dp, dev)
+    probs = eng.soft_input(g.t("s0/probs").to(dev))
+    masks = g.masks(0)
+    B, Lc = probs.shape[0], probs.shape[1]
+    l_fake, st_fake = eng.fwd(params, probs, None, True, masks[1].to(dev))
+    st_gen = eng.shared_state(st_fake, B, Lc, dev)
+    F = eng.F
+    # f32 mode is bit-reproducible; in bf16 mode the full second forward re-runs split-K products (atomic f32 sums)
+    same = torch.equal if dt == 0 else (lambda x, y: bool(torch.allclose(x.float(), y.float(), rtol=2e-2, atol=1e-4)))
+    l_gen, _ = eng.fwd_redrop(params, st_fake, st_gen, True, masks[2].to(dev))
+    l_full, st_full = eng.fwd(params, probs, None, True, masks[2].to(dev))
+    assert same(l_gen, l_full) and torch.equal(st_gen["keep"][:, :F], st_full["keep"][:, :F]) and same(st_gen["ydrop"], st_full["ydrop"])
+    # device-drawn dropout: same (seed, row, column) -> same draw on both routes
+    l_gen_p, _ = eng.fwd_redrop(params, st_fake, st_gen, True, None, seed=77)
+    l_full_p, st_full_p = eng.fwd(params, probs, None, True, None, seed=77)
+    assert same(l_gen_p, l_full_p) and torch.equal(st_gen["keep"][:, :F], st_full_p["keep"][:, :F])
+    # eval mode: no dropout, both routes give the plain forward
+    l_gen_e, _ = eng.fwd_redrop(params, st_fake, st_gen, False)
+    l_full_e, _ = eng.fwd(params, probs, None, False)
+    assert same(l_gen_e, l_full_e)
+    # backward through the aliased state
+    l_gen, _ = eng.fwd_redrop(params, st_fake, st_gen, True, masks[2].to(dev))
+    d_logits = torch.linspace(-1, 1, l_gen.numel(), device=dev)
+    _, d_a = eng.bwd(params, st_gen, probs, None, True, d_logits, False, True)
+    _, d_b = eng.bwd(params, st_full, probs, None, True, d_logits, False, True)
+    torch.cuda.synchronize()
+    if dt == 0:
+        assert torch.equal(d_a, d_b)
+    else:
+        assert rel_l2(d_a.float(), d_b.float()) < 2e-2
+    assert float(st_gen["ydrop"][:, F:].abs().max() if eng.Fp > F else 0.0) == 0.0
+
+
 # ------------------------------------------------------------------------------------------ losses / optimizer
 def test_gan_losses_all_types(E, dev):
     g = Golden("scalars")
