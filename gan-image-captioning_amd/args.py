@@ -123,7 +123,7 @@ def resolve_device(args) -> None:
     """args.py:275-278: 'cuda' -> cuda:0 when available else cpu.  Under torchrun each rank takes
     cuda:LOCAL_RANK (one process per GPU)."""
     if str(args.device).startswith("cuda") and torch.cuda.is_available():
-        args.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        args.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
     else:
         args.device = torch.device("cpu")
 

@@ -203,8 +203,16 @@ class TrunkPlan:
         else:
             self._graphs.clear()               # at most one live graph per plan: stale pointers never replay
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._run_trunk(b, N, S, training)
+            try:
+                # thread_local: other threads of the process (RCCL's watchdog polls events) may keep calling HIP during capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._run_trunk(b, N, S, training)
+            except Exception as exc:           # capture refused: keep training with eager launches (same kernels, same results)
+                import warnings
+                warnings.warn(f"hipGraph capture of the trunk forward failed ({exc}); falling back to eager launches")
+                self.use_graph = False
+                torch.cuda.synchronize()
+                return self._run_trunk(b, N, S, training)
             self._graphs[key] = g
             g.replay()
 

@@ -34,9 +34,12 @@ class DistInfo:
         if ws > 1 and init and not dist.is_initialized():
             use_gpu = torch.cuda.is_available()
             if use_gpu:
-                torch.cuda.set_device(info.local_rank)
+                # one GPU per rank; the modulo only matters for the single-GPU rehearsal (GIC_DIST_BACKEND=gloo), where
+                # several ranks share a card that RCCL would refuse
+                torch.cuda.set_device(info.local_rank % torch.cuda.device_count())
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="nccl" if use_gpu else "gloo", rank=info.rank, world_size=ws)
+            backend = os.environ.get("GIC_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+            dist.init_process_group(backend=backend, rank=info.rank, world_size=ws)
         return info
 
 
@@ -78,7 +81,7 @@ class GradReducer:
     def start(self, flat: torch.Tensor) -> None:
         if self.info.world_size <= 1:
             return
-        if not flat.is_cuda:
+        if not flat.is_cuda or dist.get_backend() == "gloo":      # gloo has no AVG; on device tensors it stages through the host
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             flat.mul_(1.0 / self.info.world_size)
             return
