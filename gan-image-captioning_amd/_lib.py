@@ -68,7 +68,7 @@ class DiscGrads(C.Structure):
 
 
 class DiscShadow(C.Structure):
-    _fields_ = [("emb", c_void_p), ("hw_w", c_void_p), ("f2o_w", c_void_p)]
+    _fields_ = [("emb", c_void_p), ("hw_w", c_void_p), ("f2o_w", c_void_p), ("hw_w_t", c_void_p)]
 
 
 class DiscState(C.Structure):

@@ -426,19 +426,6 @@ __global__ void embed_scatter_time_kernel(const float* __restrict__ dxh0, long l
 
 using namespace gic;
 
-// out[c][r] = in[r][c] for a row-major [rows, cols] matrix, 32x32 tiles through LDS (both sides coalesced)
-template <typename TA>
-__global__ void transpose2d_kernel(const TA* __restrict__ in, TA* __restrict__ out, int rows, int cols) {
-  __shared__ TA tile[32][33];
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int j = ty; j < 32; j += 8)
-    if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = in[(long)(r0 + j) * cols + c0 + tx];
-  __syncthreads();
-  for (int j = ty; j < 32; j += 8)
-    if (c0 + j < cols && r0 + tx < rows) out[(long)(c0 + j) * rows + r0 + tx] = tile[tx][j];
-}
-
 extern "C" {
 
 int gic_decoder_prepare(const gic_decoder_dims* dims, const gic_decoder_params* P, const gic_decoder_shadow* S, void* stream_) {
@@ -457,14 +444,7 @@ int gic_decoder_prepare(const gic_decoder_dims* dims, const gic_decoder_params* 
       hipLaunchKernelGGL((build_wcat_kernel<bf16_t>), dim3(grid), dim3(256), 0, stream, P->w_ih[l], P->w_hh[l], P->b_ih[l],
                          P->b_hh[l], (bf16_t*)S->wcat[l], S->bsum[l], 4 * c.H, c.din(l), c.H);
     GIC_CHECK_LAUNCH("build_wcat");
-    if (S->wcat_t[l]) {
-      const dim3 tg(cdiv(c.ldx(l), 32), cdiv(4 * c.H, 32));
-      if (c.dt == DT_F32)
-        hipLaunchKernelGGL((transpose2d_kernel<float>), tg, dim3(256), 0, stream, (const float*)S->wcat[l], (float*)S->wcat_t[l], 4 * c.H, (int)c.ldx(l));
-      else
-        hipLaunchKernelGGL((transpose2d_kernel<bf16_t>), tg, dim3(256), 0, stream, (const bf16_t*)S->wcat[l], (bf16_t*)S->wcat_t[l], 4 * c.H, (int)c.ldx(l));
-      GIC_CHECK_LAUNCH("transpose wcat");
-    }
+    if (S->wcat_t[l]) GIC_PROPAGATE(transpose2d(S->wcat[l], S->wcat_t[l], c.dt, 4 * c.H, c.ldx(l), stream));
   }
   GIC_CHECK_ARG(P->w_out && S->wout, "decoder_prepare: null w_out");
   if ((const void*)S->wout != (const void*)P->w_out)

@@ -457,7 +457,8 @@ int disc_bwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
   GIC_CHECK_LAUNCH("disc_highway_bwd");
   {
     GemmDesc g;   // dpooled += dh hw_w
-    g.A = ws->dh; g.lda = c.Fp; g.a_kc = 1; g.B = S->hw_w; g.ldb = c.Fp; g.b_kc = 0; g.C = ws->dpooled; g.ldc = c.Fp;
+    g.A = ws->dh; g.lda = c.Fp; g.a_kc = 1; g.B = S->hw_w_t ? S->hw_w_t : S->hw_w; g.ldb = c.Fp; g.b_kc = S->hw_w_t ? 1 : 0;
+    g.C = ws->dpooled; g.ldc = c.Fp;
     g.M = (int)MR; g.N = c.Fp; g.K = c.Fp; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.accumulate = 1;
     GIC_PROPAGATE(gemm(g, stream));
     if (G) {
@@ -530,6 +531,7 @@ int gic_disc_prepare(const gic_disc_dims* dims, const gic_disc_params* P, const 
   const size_t a = dtype_size(c.dt);
   GIC_PROPAGATE(fill_zero(S->hw_w, (size_t)c.Fp * c.Fp * a, stream));
   GIC_PROPAGATE(cast2d(P->hw_w, DT_F32, c.F, S->hw_w, c.dt, c.Fp, c.F, c.F, stream));
+  if (S->hw_w_t) GIC_PROPAGATE(transpose2d(S->hw_w, S->hw_w_t, c.dt, c.Fp, c.Fp, stream));
   GIC_PROPAGATE(fill_zero(S->f2o_w, (size_t)kOutPad * c.Fp * a, stream));
   GIC_PROPAGATE(cast2d(P->f2o_w, DT_F32, c.F, S->f2o_w, c.dt, c.Fp, kOutDim, c.F, stream));
   return GIC_OK;

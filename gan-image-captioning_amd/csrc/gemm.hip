@@ -668,13 +668,24 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
   // of outstanding DMAs is the same in every iteration.
   const int nk = (K + BK - 1) / BK;
   STAMP(1);
+  if constexpr (NS == 1) {
+    // shallow K (one or two tiles): no ring; the LDS footprint is the C tile's, so up to four blocks share a CU and hide
+    // each other's load latency and epilogue
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt) __builtin_amdgcn_s_barrier();            // every wave is done reading the previous tile
+      issue(kt, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      compute(0);
+    }
+  } else {
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) issue(s, s);
   int st = 0, st_fill = NS - 1;
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt has landed once all but this wave's newest (NS-2) tiles are done; the barrier publishes every wave's part
     // and retires all reads of the stage refilled next (it was computed on in iteration kt-1)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NL) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS >= 2 ? (NS - 2) * NL : 0) : "memory");
     __builtin_amdgcn_s_barrier();
     if (kt == 0) STAMP(2);
     if (!(DBG & 1)) issue(kt + NS - 1, st_fill);
@@ -682,12 +693,52 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
     st = st == NS - 1 ? 0 : st + 1;
     st_fill = st_fill == NS - 1 ? 0 : st_fill + 1;
   }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stray zero-fill DMAs must not land in the C tile
   __syncthreads();
   STAMP(3);
 
-  // ---- epilogue: C tile through LDS (16-byte row stores), BatchNorm column sums folded across the block
   TO* __restrict__ C = (TO*)d.C;
+  if constexpr (EPI == EPI_HIGHWAY) {
+    // h = acc + bias (saved); y = sig(h) relu(h) + (1 - sig(h)) x; C = y * keep * keep_scale.  Per-element stores of the MFMA
+    // layout (as in gemm_kernel): X / Hpre / mask traffic dominates this epilogue, not the store shape.
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = bn0 + wc * (BN / 2) + j * 16 + lr;
+        if (n >= N) continue;
+        const float bias = d.bias ? d.bias[n] : 0.f;
+        const int mb = bm0 + wr * 32 + i * 16 + lg * 4;
+        float keep4[4] = {1.f, 1.f, 1.f, 1.f};
+        if (!d.mask && d.use_philox) {       // one Philox4x32 call serves the lane's 4 consecutive rows
+          uint32_t r0, r1, r2, r3;
+          Philox::gen4(d.seed, d.stream, (uint64_t)(mb >> 2) * (uint64_t)N + (uint64_t)n, r0, r1, r2, r3);
+          keep4[0] = Philox::u01(r0) >= d.drop_p ? 1.f : 0.f;
+          keep4[1] = Philox::u01(r1) >= d.drop_p ? 1.f : 0.f;
+          keep4[2] = Philox::u01(r2) >= d.drop_p ? 1.f : 0.f;
+          keep4[3] = Philox::u01(r3) >= d.drop_p ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = mb + r;
+          if (m >= M) continue;
+          const float v = d.alpha * acc[i][j][r] + bias;
+          const float x = to_f32<bf16_t>(((const bf16_t*)d.X)[(long)m * d.ldx + n]);
+          const float sg = 1.f / (1.f + expf(-v));
+          const float y = sg * fmaxf(v, 0.f) + (1.f - sg) * x;
+          d.Hpre[(long)m * d.ldh + n] = v;
+          float keep = keep4[r];
+          if (d.mask) keep = (float)d.mask[(long)m * d.ldmask + n];
+          if (d.mask_out) d.mask_out[(long)m * d.ldmask_out + n] = (uint8_t)keep;
+          C[(long)m * d.ldc + n] = from_f32<TO>(y * keep * d.keep_scale);
+        }
+      }
+    }
+    STAMP(5);
+    return;
+  }
+  // ---- epilogue: C tile through LDS (16-byte row stores), BatchNorm column sums folded across the block
   unsigned char* sC = smem;
   float* sStat = (float*)(smem + BM * SC);                   // [8 waves][BN/2][2]
 #pragma unroll
@@ -734,7 +785,17 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
   for (int c = tid; c < BM * CPR; c += NT) {
     const int ml = c / CPR, cc = c % CPR;
     const int m = bm0 + ml, n = bn0 + cc * OVE;
-    if (m < M && n < N) *(u32x4*)(C + (long)m * d.ldc + n) = *(const u32x4*)(sC + ml * SC + cc * 16);
+    if (m < M && n < N) {
+      u32x4 v = *(const u32x4*)(sC + ml * SC + cc * 16);
+      if (d.accumulate) {                                    // C += result (f32 gradients accumulated across passes)
+        const u32x4 o = *(const u32x4*)(C + (long)m * d.ldc + n);
+        TO* pv = (TO*)&v;
+        const TO* po = (const TO*)&o;
+#pragma unroll
+        for (int e = 0; e < OVE; ++e) pv[e] = from_f32<TO>(to_f32<TO>(pv[e]) + to_f32<TO>(po[e]));
+      }
+      *(u32x4*)(C + (long)m * d.ldc + n) = v;
+    }
   }
   STAMP(5);
 }
@@ -745,7 +806,11 @@ template <typename TO, int EPI, bool CONV>
 bool try_tile8(const GemmDesc& d, hipStream_t stream) {
   static const bool off = getenv("GIC_NO_TILE8") != nullptr;
   constexpr int OVE = 16 / (int)sizeof(TO);
-  if (off || d.accumulate || d.M < 128 || (d.N % OVE) || (d.ldc % OVE) || (((uintptr_t)d.C) & 15)) return false;
+  if (off || d.M < 128) return false;
+  if (EPI != EPI_HIGHWAY && ((d.N % OVE) || (d.ldc % OVE) || (((uintptr_t)d.C) & 15))) return false;
+  if (EPI == EPI_HIGHWAY && d.in_dtype != DT_BF16) return false;
+  // a plain product must fill the chip with 128-row tiles and be deep enough to amortise the ring (else: gemm_kernel, split-K)
+  if (!CONV && ((long)cdiv(d.M, 128) * cdiv(d.N, 64) < 128 || d.K < 256)) return false;
   const long a_elems = CONV ? (long)(d.M / (d.cHo * d.cWo)) * d.cH * d.cW * d.cCin : (long)(d.M - 1) * d.lda + d.K;
   const long b_elems = (long)(d.N - 1) * d.ldb + d.K;
   if (a_elems * 2 >= (1l << 31) || b_elems * 2 >= (1l << 31)) return false;
@@ -757,6 +822,13 @@ bool try_tile8(const GemmDesc& d, hipStream_t stream) {
   const unsigned ab = (unsigned)(a_elems * 2), bb = (unsigned)(b_elems * 2);
   // deep ring (4 stages, 128 KB: one block per CU) when the grid is about one block per CU; with several blocks per CU a
   // 2-stage ring (64 KB) lets two blocks share the CU so one block's epilogue runs under the other's K loop
+  static const int ns1_nk = [] { const char* e = getenv("GIC_TILE8_NS1_NK"); return e ? atoi(e) : 4; }();
+  const int nk8 = cdiv(d.K, 64);
+  if (EPI != EPI_HIGHWAY && nk8 <= ns1_nk && (d.N >= 128 ? big_tiles : (long)cdiv(d.M, 128) * cdiv(d.N, 64)) > 512) {
+    if (d.N >= 128) hipLaunchKernelGGL((tile8_kernel<TO, 128, EPI, CONV, 1>), dim3((unsigned)big_tiles), dim3(512), 0, stream, d, ab, bb);
+    else hipLaunchKernelGGL((tile8_kernel<TO, 64, EPI, CONV, 1>), dim3((unsigned)(cdiv(d.M, 128) * cdiv(d.N, 64))), dim3(512), 0, stream, d, ab, bb);
+    return true;
+  }
   if (d.N >= 128 && big_tiles >= big_min) {
     if (big_tiles > ns2_tiles) hipLaunchKernelGGL((tile8_kernel<TO, 128, EPI, CONV, 2>), dim3((unsigned)big_tiles), dim3(512), 0, stream, d, ab, bb);
     else hipLaunchKernelGGL((tile8_kernel<TO, 128, EPI, CONV, 4>), dim3((unsigned)big_tiles), dim3(512), 0, stream, d, ab, bb);
@@ -841,6 +913,9 @@ int pick_tile(const GemmDesc& d, bool vec, hipStream_t stream) {
 
 template <typename TI, typename TO, int EPI>
 int pick_layout(const GemmDesc& d, bool vec, hipStream_t stream) {
+  if constexpr (sizeof(TI) == 2) {
+    if (d.a_kc && d.b_kc && vec && try_tile8<TO, EPI, false>(d, stream)) { GIC_CHECK_LAUNCH("gemm tile8"); return GIC_OK; }
+  }
   if (d.a_kc && d.b_kc) return pick_tile<TI, TO, true, true, EPI>(d, vec, stream);
   if constexpr (EPI == EPI_PLAIN) {
     if (d.a_kc && !d.b_kc) return pick_tile<TI, TO, true, false, EPI>(d, vec, stream);

@@ -15,5 +15,7 @@ int embedding_fwd(const float* weight, const int64_t* ids, float* out, long n, i
 int embedding_bwd(const float* d_out, const int64_t* ids, float* d_weight, long n, int V, int E, int zero_first,
                   hipStream_t stream);
 int fill_zero(void* p, size_t bytes, hipStream_t stream);
+// dst[c][r] = src[r][c] for a row-major [rows, cols] matrix of `dtype`
+int transpose2d(const void* src, void* dst, int dtype, long rows, long cols, hipStream_t stream);
 
 }  // namespace gic

@@ -19,6 +19,19 @@ void set_last_error(const char* fmt, ...) {
 namespace {
 
 // ---- 2-D cast/copy: one thread per element, coalesced along columns
+// out[c][r] = in[r][c] for a row-major [rows, cols] matrix, 32x32 tiles through LDS (both sides coalesced)
+template <typename TA>
+__global__ void transpose2d_kernel(const TA* __restrict__ in, TA* __restrict__ out, int rows, int cols) {
+  __shared__ TA tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8)
+    if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = in[(long)(r0 + j) * cols + c0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (c0 + j < cols && r0 + tx < rows) out[(long)(c0 + j) * rows + r0 + tx] = tile[tx][j];
+}
+
 template <typename TS, typename TD>
 __global__ void cast2d_kernel(const TS* __restrict__ src, long lds, TD* __restrict__ dst, long ldd, long rows, long cols) {
   const long total = rows * cols;
@@ -77,6 +90,17 @@ inline int grid_for(long total, int block = 256, int cap = 2048) {
 }
 
 }  // namespace
+
+int transpose2d(const void* src, void* dst, int dtype, long rows, long cols, hipStream_t stream) {
+  GIC_CHECK_ARG(src && dst && rows > 0 && cols > 0, "transpose2d: bad argument");
+  const dim3 tg((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32));
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL((transpose2d_kernel<float>), tg, dim3(256), 0, stream, (const float*)src, (float*)dst, (int)rows, (int)cols);
+  else
+    hipLaunchKernelGGL((transpose2d_kernel<bf16_t>), tg, dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, (int)rows, (int)cols);
+  GIC_CHECK_LAUNCH("transpose2d");
+  return GIC_OK;
+}
 
 int fill_zero(void* p, size_t bytes, hipStream_t stream) {
   if (bytes == 0) return GIC_OK;

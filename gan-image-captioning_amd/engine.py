@@ -357,6 +357,8 @@ class DiscEngine:
                 "emb": None if self.dt == L.F32 else torch.empty(self.De, self.V, device=dev, dtype=self.act),
                 "hw_w": torch.empty(self.Fp, self.Fp, device=dev, dtype=self.act),
                 "f2o_w": torch.empty(self.OUT_PAD, self.Fp, device=dev, dtype=self.act),
+                # bf16 mode: highway^T so that the input-gradient product d_pooled += dh W runs on k-contiguous operands
+                "hw_w_t": None if self.dt == L.F32 else torch.empty(self.Fp, self.Fp, device=dev, dtype=self.act),
             }
         d = self.dims(1, max(self.fs))
         L.check(L.load().gic_disc_prepare(C.byref(d), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)),
@@ -369,6 +371,7 @@ class DiscEngine:
         s = L.DiscShadow()
         s.emb = ptr(params[0]) if sh["emb"] is None else ptr(sh["emb"])
         s.hw_w, s.f2o_w = ptr(sh["hw_w"]), ptr(sh["f2o_w"])
+        s.hw_w_t = ptr(sh["hw_w_t"])
         return s
 
     def alloc_state(self, B: int, Lc: int, dev):

@@ -171,6 +171,8 @@ typedef struct gic_disc_shadow {         /* compute-dtype weight images (may ali
   void* emb;                             /* act [De,V] */
   void* hw_w;                            /* act [F,F]  */
   void* f2o_w;                           /* act [100,F] */
+  void* hw_w_t;                          /* act [Fp,Fp] = highway^T, the k-contiguous operand of the highway input-gradient
+                                            product; NULL: that product reads hw_w transposed instead */
 } gic_disc_shadow;
 
 typedef struct gic_disc_state {          /* saved-for-backward of one forward call (caller-owned) */
