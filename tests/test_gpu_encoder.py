@@ -51,6 +51,8 @@ def conv_hip(x_nchw, w, stride, pad, dtype, dev, want_stats=True):
 CONV_CASES = [  # (N, Cin, H, Cout, k, stride, pad)
     (2, 64, 16, 64, 3, 1, 1), (2, 64, 16, 128, 3, 2, 1), (3, 64, 8, 256, 1, 1, 0), (2, 128, 8, 64, 1, 2, 0),
     (1, 256, 7, 512, 3, 1, 1), (4, 64, 56, 64, 3, 1, 1), (2, 512, 4, 2048, 1, 1, 0), (2, 8, 10, 24, 3, 1, 1),
+    # grids past one / two workgroups per CU: the 2-stage ring and the ring-less shallow-K variant of the 8-wave kernel
+    (16, 64, 56, 128, 1, 1, 0), (32, 64, 56, 64, 1, 1, 0), (12, 128, 28, 256, 3, 1, 1),
 ]
 
 

@@ -469,6 +469,43 @@ def test_bf16_decoder_and_disc_close_to_f32_oracle(E, dev):
     assert max(errs.values()) < 6e-2, errs      # conv/emb grads also carry re-routed max-pool near-ties
 
 
+def test_bf16_discriminator_at_bench_batch(E, dev):
+    """B = 32 rows x 64 representations: the highway product (forward epilogue with dropout, input gradient on the transposed
+    weight image, accumulating weight gradients with split-K) runs on the 8-wave kernel, as in the benchmark; checked against
+    the fp32 oracle on its own inputs."""
+    g = Golden("cfg1")
+    _, dp = initial_params(g)
+    m = g.meta
+    B, Lc, V = 32, 12, m["V"]
+    rg = torch.Generator().manual_seed(21)
+    probs = torch.softmax(torch.randn(B, Lc, V, generator=rg) * 3, -1)
+    mask = (torch.rand(B * m["R"], 900, generator=rg) >= 0.2).to(torch.uint8)
+    dnames = disc_param_names(len(m["nf"]))
+    dleaf = {k: dp[k].clone().requires_grad_(True) for k in dnames}
+    p_leaf = probs.clone().requires_grad_(True)
+    o = O.disc_forward(dleaf, p_leaf, mask, m["R"])
+    dl = torch.randn(o.shape, generator=rg)
+    (o * dl).sum().backward()
+    deng = _disc(E, m, 1)
+    dparams = disc_params(dp, dev)
+    sd = deng.soft_input(probs.to(dev))
+    lg, dst = deng.fwd(dparams, sd, None, True, mask.to(dev))
+    dgr, d_inp = deng.bwd(dparams, dst, sd, None, True, dl.to(dev), True, True)
+    # second pass accumulates on top of the first (the step's real + fake passes): gradients double
+    dgr2, _ = deng.bwd(dparams, dst, sd, None, True, dl.to(dev), True, False, grads=[t.clone() for t in dgr], accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.equal(dst["keep"][:, :900].cpu(), mask)
+    errs = {n: rel_l2(gt, dleaf[n].grad) for n, gt in zip(dnames, dgr)}
+    errs["logits"] = rel_l2(lg, o)
+    errs["d_inp"] = rel_l2(d_inp.float(), p_leaf.grad)
+    print("bf16 discriminator (B=32) rel-L2 errors:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert errs["logits"] < 2e-2, errs
+    for n, e in errs.items():        # conv / embedding / input gradients also carry re-routed max-pool near-ties (bf16 pooled values)
+        assert e < (8e-2 if n.startswith(("convs", "embeddings", "d_inp")) else 3e-2), (n, errs)
+    for n, g1, g2 in zip(dnames, dgr, dgr2):
+        assert rel_l2(g2, 2 * g1) < 2e-2, n
+
+
 def test_no_cpu_fallback(E):
     """The product path refuses CPU tensors instead of silently computing elsewhere."""
     from gan_image_captioning_amd._lib import GicError
