@@ -20,7 +20,7 @@ from . import engine
 from .engine import ptr, stream_ptr
 
 AVAILABLE = True
-STATS_REPLICAS = 8       # BatchNorm sum replicas: conv workgroup b adds into replica b % 16 (global f32 atomics serialise per address)
+STATS_REPLICAS = 8       # BatchNorm sum replicas (arena spacing): conv workgroup b adds into replica b % nrep (global f32 atomics serialise per address)
 
 
 def _check(status, what):
@@ -62,6 +62,7 @@ class TrunkPlan:
         self._bufs: Dict[Tuple[int, int], dict] = {}
         self._graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
         self._warm: set = set()
+        self._nrep = {}
         self.use_graph = not os.environ.get("GIC_NO_GRAPH")
         self.pending_tracked = 0
 
@@ -94,6 +95,7 @@ class TrunkPlan:
     def _buffers(self, N: int, S: int, dev) -> dict:
         key = (N, S)
         if key in self._bufs:
+            self._nrep = self._bufs[key]["nrep"]
             return self._bufs[key]
         act = self.act
         b: dict = {"stats": torch.zeros(self.stats_len, device=dev, dtype=torch.float32)}
@@ -132,6 +134,12 @@ class TrunkPlan:
         b["blocks"] = blocks
         b["feat"] = torch.empty(N, self.trunk.out_features, device=dev, dtype=act)
         b["rows"] = rows
+        # replicas actually used per layer: many workgroups -> 8 (atomic contention), few -> 2 (every bn_act block folds all of them)
+        lo, mid = (int(v) for v in os.environ.get("GIC_STATS_NREP", "2,4").split(","))
+        b["nrep"] = {}
+        for s in self.steps:
+            tiles = -(-rows[s.name] // 128) * -(-s.cout // 128)
+            b["nrep"][s.name] = STATS_REPLICAS if tiles > 1024 else (mid if tiles > 256 else lo)
         # device table for the one-launch running-statistics update
         table = (L.BnRunningDesc * len(self.steps))()
         for i, s in enumerate(self.steps):
@@ -141,16 +149,17 @@ class TrunkPlan:
             table[i].count = float(rows[s.name])
             table[i].momentum = float(s.bn.momentum)
             table[i].C = s.cout
-            table[i].nrep = STATS_REPLICAS
+            table[i].nrep = b["nrep"][s.name]
         raw = bytes(table)
         b["table"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self._bufs[key] = b
+        self._nrep = b["nrep"]
         return b
 
     # ---------------------------------------------------------------- kernels
     def _conv(self, s: _ConvStep, x: torch.Tensor, y: torch.Tensor, stats: Optional[torch.Tensor], N, H, W, cin=None, kw=None, pad=None):
         st = None if stats is None else stats.data_ptr() + 4 * s.stats_off
-        _check(L.load().gic_conv2d(ptr(x), ptr(s.w), ptr(y), st, STATS_REPLICAS, self.dtype, N, H, W, cin if cin is not None else s.cin, s.cout, s.k,
+        _check(L.load().gic_conv2d(ptr(x), ptr(s.w), ptr(y), st, self._nrep[s.name], self.dtype, N, H, W, cin if cin is not None else s.cin, s.cout, s.k,
                                    kw if kw is not None else s.k, s.stride, pad if pad is not None else s.pad, stream_ptr()), "gic_conv2d " + s.name)
 
     def _bn_args(self, s: Optional[_ConvStep], stats: Optional[torch.Tensor], training: bool):
@@ -165,7 +174,7 @@ class TrunkPlan:
     def _bn_act(self, s, y, out, stats, training, rows, relu=True, res=None, res_step=None):
         a = self._bn_args(s, stats, training)
         r = self._bn_args(res_step, stats, training)
-        _check(L.load().gic_bn_act(ptr(y), *a, ptr(res), *r, STATS_REPLICAS, float(rows), int(relu), ptr(out), self.dtype, rows, s.cout, stream_ptr()),
+        _check(L.load().gic_bn_act(ptr(y), *a, ptr(res), *r, self._nrep[s.name], float(rows), int(relu), ptr(out), self.dtype, rows, s.cout, stream_ptr()),
                "gic_bn_act " + s.name)
 
     def forward(self, images: torch.Tensor, training: bool) -> torch.Tensor:
@@ -226,7 +235,7 @@ class TrunkPlan:
         self._conv(self.stem, b["xin"], b["y0"], stats, N, S + 6, S + 6, cin=4, kw=8, pad=0)
         h = b["y0"].shape[1]
         a = self._bn_args(self.stem, stats, training)
-        _check(lib.gic_bn_relu_maxpool(ptr(b["y0"]), *a, STATS_REPLICAS, float(rows[self.stem.name]), ptr(b["x0"]), self.dtype, N, h, h, 64, stream_ptr()),
+        _check(lib.gic_bn_relu_maxpool(ptr(b["y0"]), *a, self._nrep[self.stem.name], float(rows[self.stem.name]), ptr(b["x0"]), self.dtype, N, h, h, 64, stream_ptr()),
                "gic_bn_relu_maxpool")
         x = b["x0"]
         for blk, e in zip(self.blocks, b["blocks"]):
