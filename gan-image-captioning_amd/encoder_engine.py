@@ -348,7 +348,7 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None):
         if key not in seen:
             seen[key] = [event_time_ms(lambda: plan._conv(s, xi, yo, b["stats"], N, H, W, **kw), 5, stream), 0, macs, s.name]
         seen[key][1] += 1
-    total_ms = total_flops = bound_us = 0.0
+    total_ms = total_flops = bound_us = total_bytes = 0.0
     launches = 0
     layers = []
     for key, (ms, count, macs, name) in seen.items():
@@ -361,6 +361,7 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None):
         nbytes = 2.0 * (N * key[4] * key[4] * key[0] + N * Ho * Ho * key[1] + key[0] * key[1] * key[2] * key[2])
         floor_us = max(2.0 * macs / (peak_tflops * 1e12), nbytes / 8e12) * 1e6
         bound_us += floor_us * count
+        total_bytes += nbytes * count
         print(f"[conv] {name:22s} Cin={key[0]:5d} Cout={key[1]:5d} k={key[2]} s={key[3]} H={key[4]:4d} x{count}: {ms * 1e3:8.1f} us {tf:7.1f} TFLOP/s "
               f"{nbytes / (ms * 1e-3) / 1e9:7.0f} GB/s  roofline floor {floor_us:6.1f} us", file=sys.stderr)
     print(f"[conv] all {launches} launches: {total_ms * 1e3:.1f} us; per-layer max(MFMA, HBM) floor {bound_us:.1f} us", file=sys.stderr)
@@ -372,4 +373,7 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None):
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(achieved / peak_tflops, 4),
             "traffic": pmc_traffic, "ms_per_launch": round(total_ms / launches, 5), "launches_per_step": launches,
             "ms_per_step": round(total_ms, 4), "algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
+            "algorithmic_bytes_per_launch": int(total_bytes / launches),
+            "floor_ms_per_step": round(bound_us / 1e3, 4),      # sum over layers of max(flops / MFMA peak, bytes / 8 TB/s)
+            "frac_of_floor": round(bound_us / 1e3 / total_ms, 4),
             "slowest_layer": fmt(layers[0]), "fastest_layer": fmt(layers[-1])}
