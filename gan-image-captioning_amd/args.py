@@ -77,7 +77,6 @@ _NATIVE = [
     ("--synthetic-batches", int, 8, "batches per epoch of the synthetic dataset"),
     ("--synthetic-caption-len", int, 20, "caption length (incl. <S>/<E>) of synthetic batches"),
     ("--seed", int, 1008, "RNG seed (src/main.py:14 fixes 1008)"),
-    ("--bn-sync", int, 1, "data-parallel: all-reduce BatchNorm statistics across ranks", {"choices": [0, 1]}),
     ("--num-workers", int, 4, "DataLoader workers (training.py:28-32 uses 4)"),
 ]
 
