@@ -76,6 +76,8 @@ _NATIVE = [
     ("--synthetic", int, 0, "use synthetic (image, caption) batches instead of COCO", {"choices": [0, 1]}),
     ("--synthetic-batches", int, 8, "batches per epoch of the synthetic dataset"),
     ("--synthetic-caption-len", int, 20, "caption length (incl. <S>/<E>) of synthetic batches"),
+    ("--resume", str, "", "checkpoint to start from: adv_model.ckpt ({generator, discriminator}) or pretrained_model.ckpt "
+                          "(generator state dict), in the reference's format (training.py:118,225-226); the reference cannot resume"),
     ("--seed", int, 1008, "RNG seed (src/main.py:14 fixes 1008)"),
     ("--num-workers", int, 4, "DataLoader workers (training.py:28-32 uses 4)"),
 ]

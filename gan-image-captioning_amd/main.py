@@ -39,6 +39,8 @@ def main(argv=None):
         val = COCO_data(args.data_dir + "/dataset_coco.json", args.data_dir, "val", args.image_size, args.captions_per_image,
                         vocab_dicts=(train.word_to_index, train.index_to_word), dataset_percent=args.dataset_percent)
     inst = GANInstructor(args, train, val)
+    if getattr(args, "resume", ""):
+        inst.load_checkpoint(args.resume)
     inst._run()
     return inst
 

@@ -245,6 +245,23 @@ class GANInstructor:
                 self.update_temperature(self.adv_epoch + float_epoch / len(loader), self.args.adv_epochs)   # training.py:183
         return np.mean(gen_loss), np.mean(disc_loss)
 
+    def load_checkpoint(self, path: str) -> str:
+        """Load weights written by ``_run`` here or by the reference (training.py:118: the generator's state dict;
+        training.py:225-226: {"generator", "discriminator"}).  Values are copied into the existing parameter storage (the flat
+        arenas stay in place); optimizer moments start from zero, as after the reference's own cold start.  Returns the kind."""
+        ckpt = torch.load(path, map_location=self.args.device)
+        if isinstance(ckpt, dict) and set(ckpt) == {"generator", "discriminator"}:
+            self.gen.load_state_dict(ckpt["generator"])
+            self.disc.load_state_dict(ckpt["discriminator"])
+            kind = "adversarial"
+        else:
+            self.gen.load_state_dict(ckpt)
+            kind = "pretrained"
+        from . import engine
+        engine.bump_param_epoch()          # compute-dtype weight images are stale
+        self.log.info("resumed %s weights from %s", kind, path)
+        return kind
+
     def _save(self, obj, name):
         if self.model_dir and self.dist.rank == 0:
             torch.save(obj, os.path.join(self.model_dir, name))

@@ -100,3 +100,34 @@ def test_checkpoint_roundtrip_reproduces_the_step():
     torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-6, atol=0)
     torch.testing.assert_close(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(outs[0][3], outs[1][3], rtol=1e-5, atol=1e-7)
+
+
+def test_resume_from_reference_format_checkpoint(tmp_path):
+    """--resume: weights saved in the reference's checkpoint layout come back bit-identical (generator incl. the trunk's
+    BatchNorm buffers, discriminator), and the run continues from them."""
+    from gan_image_captioning_amd.main import main
+    base = ["--synthetic", "1", "--synthetic-batches", "2", "--synthetic-caption-len", "8", "--vocab-size", "64",
+            "--adv-train-batch-size", "4", "--adv-eval-batch-size", "4", "--adv-epochs", "1", "--pretrain-epochs", "0",
+            "--gen-hidden-dim", "32", "--gen-embed-dim", "16", "--image-size", "32", "--conditional-gan", "1",
+            "--encoder-arch", "resnet18", "--save-dir", str(tmp_path), "--num-workers", "0", "--compute-dtype", "bf16"]
+    first = main(base + ["--expt-name", "a"])
+    torch.cuda.synchronize()
+    ckpt = os.path.join(str(tmp_path), "a_1", "models", "adv_model.ckpt")
+    saved = torch.load(ckpt, map_location="cpu")
+    from gan_image_captioning_amd.args import get_args
+    from gan_image_captioning_amd.training import GANInstructor
+    args = get_args(base + ["--expt-name", "b", "--resume", ckpt])
+    args.vocab_size = 64
+    inst = GANInstructor(args, None, None)
+    assert inst.load_checkpoint(ckpt) == "adversarial"
+    for k, v in inst.gen.state_dict().items():
+        assert torch.equal(v.cpu(), saved["generator"][k]), k
+    for k, v in inst.disc.state_dict().items():
+        assert torch.equal(v.cpu(), saved["discriminator"][k]), k
+    # a pre-train checkpoint is the bare generator state dict (training.py:118)
+    gen_only = os.path.join(str(tmp_path), "gen_only.ckpt")
+    torch.save(first.gen.state_dict(), gen_only)
+    assert inst.load_checkpoint(gen_only) == "pretrained"
+    second = main(base + ["--expt-name", "c", "--resume", ckpt])
+    torch.cuda.synchronize()
+    assert int(second.gen_opt.step_count) == 2
