@@ -664,6 +664,29 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
   };
 
+  // fragment reads / MFMAs of one 32-deep half (ks) of a K tile, as separate phases for the software pipeline below
+  auto read_half = [&](int st, int ks, bf16x8 (&fa)[TM], bf16x8 (&fb)[TN]) {
+    const unsigned char* sA = smem + st * STAGE;
+    const unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      const int row = wr * 32 + t * 16 + lr;
+      fa[t] = *(const bf16x8*)(sA + row * 128 + (((ks * 4 + lg) ^ ((row >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const int row = wc * (BN / 2) + t * 16 + lr;
+      fb[t] = *(const bf16x8*)(sB + row * 128 + (((ks * 4 + lg) ^ ((row >> 1) & 7)) << 4));
+    }
+  };
+  auto mfma_half = [&](const bf16x8 (&fa)[TM], const bf16x8 (&fb)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+  };
+
   // ---- K loop: NS-1 tiles in flight.  Tiles past the end of K are all-OOB DMAs (zero fill, no traffic), so the count
   // of outstanding DMAs is the same in every iteration.
   const int nk = (K + BK - 1) / BK;
@@ -678,21 +701,50 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
       __builtin_amdgcn_s_barrier();
       compute(0);
     }
+  } else if constexpr (NS < 4) {
+    // 2-stage ring: two workgroups share the CU and cover each other's phases; the plain loop measures faster here
+    issue(0, 0);
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                      // stage kt published; every wave is done reading stage kt-1
+      if (kt == 0) STAMP(2);
+      if (!(DBG & 1)) issue(kt + 1, st ^ 1);
+      if (!(DBG & 2)) compute(st);
+      st ^= 1;
+    }
   } else {
+    // Software pipeline across K tiles: the second half's fragments of tile kt-1 stay in registers over the barrier, so that
+    // every MFMA phase has the next phase's LDS reads in flight under it (all 8 waves leave the barrier in lockstep: without
+    // this the CU alternates between an LDS-read phase and an MFMA phase):
+    //     barrier | read A(kt) | mfma B(kt-1) | DMA(kt+NS-1) | read B(kt) | mfma A(kt)       A / B = 32-deep halves
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s) issue(s, s);
-  int st = 0, st_fill = NS - 1;
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed once all but this wave's newest (NS-2) tiles are done; the barrier publishes every wave's part
-    // and retires all reads of the stage refilled next (it was computed on in iteration kt-1)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS >= 2 ? (NS - 2) * NL : 0) : "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt == 0) STAMP(2);
-    if (!(DBG & 1)) issue(kt + NS - 1, st_fill);
-    if (!(DBG & 2)) compute(st);
-    st = st == NS - 1 ? 0 : st + 1;
-    st_fill = st_fill == NS - 1 ? 0 : st_fill + 1;
-  }
+    for (int s = 0; s < NS - 1; ++s) issue(s, s);
+    bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    int st = 0, st_fill = NS - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+      // stage kt has landed once all but this wave's newest (NS-2) tiles are done.  This wave's reads of stage kt-1 (their
+      // data is needed below anyway) must have returned before the barrier lets anyone refill that stage.
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NS >= 2 ? (NS - 2) * NL : 0) : "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt == 0) STAMP(2);
+      if (!(DBG & 2)) {
+        read_half(st, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt > 0) mfma_half(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!(DBG & 1)) issue(kt + NS - 1, st_fill);
+      if (!(DBG & 2)) {
+        __builtin_amdgcn_sched_barrier(0);
+        read_half(st, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(fa0, fb0);
+      }
+      st = st == NS - 1 ? 0 : st + 1;
+      st_fill = st_fill == NS - 1 ? 0 : st_fill + 1;
+    }
+    if (!(DBG & 2) && nk > 0) mfma_half(fa1, fb1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stray zero-fill DMAs must not land in the C tile
   __syncthreads();
