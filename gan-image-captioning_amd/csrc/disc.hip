@@ -9,6 +9,7 @@
 // Activations [B*R, Fp] keep a zero-padded leading dim Fp (multiple of 8) so the bf16 GEMMs
 // can use 16-byte chunks along K; pad columns are zero (written by these kernels or, for
 // `ydrop`, left from a zero-initialised allocation - the GEMM epilogue never touches them).
+#include <stdlib.h>
 #include "../../include/gicap.h"
 #include "kernels.h"
 
@@ -180,6 +181,57 @@ __global__ __launch_bounds__(256) void disc_conv_pool_bwd_x_kernel(const float* 
     float acc = 0.f;
     for (int g = 0; g < NG; ++g) acc += part[g * n_out + o];
     demb[((long)b * L + o / s) * De + r * s + o % s] = from_f32<TA>(acc);
+  }
+}
+
+// Same result for few outputs per row (n_out = L*s <= MAXO, e.g. s = 1) and short windows (taps <= MAXT): a thread owns F/256
+// filters with their weights in registers and scatters g*w into ITS OWN column of an LDS sheet part[o][thread] (no other
+// thread touches that column: plain adds, no atomics, bank = thread id -> conflict-free); the sheet is then folded per output
+// in a fixed order (deterministic).  A block serves `rpb` rows with the same registers.
+template <typename TA, int MAXO, int MAXT>
+__global__ __launch_bounds__(256) void disc_conv_pool_bwd_x_small_kernel(const float* __restrict__ dpooled, const TA* __restrict__ pooled,
+                                                                           const uint8_t* __restrict__ argmax, ConvMeta cm, int L, int De,
+                                                                           int R, TA* __restrict__ demb, int rows, int rpb) {
+  __shared__ float part[MAXO][256];
+  const int s = cm.s, n_out = L * s;
+  constexpr int FPT = 4;                             // filters per thread (F <= 1024)
+  int f_taps[FPT];
+  float f_w[FPT][MAXT];
+#pragma unroll
+  for (int i = 0; i < FPT; ++i) {
+    const int col = threadIdx.x + i * 256;
+    f_taps[i] = 0;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) f_w[i][j] = 0.f;
+    if (col < cm.F) {
+      const int k = conv_of(cm, col);
+      f_taps[i] = cm.fsize[k] * s;
+      const float* wp = cm.w[k] + (long)(col - cm.foff[k]) * f_taps[i];
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) if (j < f_taps[i]) f_w[i][j] = wp[j];
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int br = blockIdx.x * rpb; br < (blockIdx.x + 1) * rpb && br < rows; ++br) {
+    const int b = br / R, r = br % R;
+    for (int o = 0; o < n_out; ++o) part[o][threadIdx.x] = 0.f;
+#pragma unroll
+    for (int i = 0; i < FPT; ++i) {
+      const int col = threadIdx.x + i * 256;
+      if (col >= cm.F) continue;
+      const long idx = (long)br * cm.Fp + col;
+      const float g = to_f32<TA>(pooled[idx]) > 0.f ? dpooled[idx] : 0.f;     // relu gate
+      const int t0 = (int)argmax[idx] * s;           // output index of the window's first tap
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j)
+        if (j < f_taps[i] && t0 + j < n_out) part[t0 + j][threadIdx.x] += g * f_w[i][j];
+    }
+    __syncthreads();
+    for (int o = w; o < n_out; o += 4) {             // wave w folds outputs w, w+4, ...: 4 columns per lane, then the wave
+      const float v = wave_sum(part[o][lane] + part[o][lane + 64] + part[o][lane + 128] + part[o][lane + 192]);
+      if (lane == 0) demb[((long)b * L + o / s) * De + r * s + o % s] = from_f32<TA>(v);
+    }
+    __syncthreads();
   }
 }
 
@@ -488,8 +540,18 @@ int disc_bwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
   for (int k = 0; k < c.cm.nconv; ++k) conv_w_total += (size_t)c.cm.nfilt[k] * c.cm.fsize[k] * c.s;
   const size_t bwd_x_lds = ((size_t)3 * c.Fp + (size_t)(n_out >= 256 ? 1 : 256 / n_out) * n_out + conv_w_total) * sizeof(float);
   GIC_CHECK_ARG(bwd_x_lds <= 160 * 1024, "disc_bwd: conv weights (%zu floats) do not fit the LDS staging", conv_w_total);
-  hipLaunchKernelGGL((disc_conv_pool_bwd_x_kernel<TA>), dim3((unsigned)MR), dim3(256), bwd_x_lds, stream,
-                     (const float*)ws->dpooled, (const TA*)st->pooled, (const uint8_t*)st->argmax, c.cm, c.L, c.De, c.R, (TA*)ws->demb);
+  int max_taps_x = 0;
+  for (int k = 0; k < c.cm.nconv; ++k) max_taps_x = c.cm.fsize[k] * c.s > max_taps_x ? c.cm.fsize[k] * c.s : max_taps_x;
+  if (n_out <= 32 && c.F <= 1024 && max_taps_x <= 8) {
+    static const int rpb_env = [] { const char* e = getenv("GIC_BWDX_RPB"); return e ? atoi(e) : 0; }();
+    const int rpb = rpb_env > 0 ? rpb_env : (MR >= 2048 ? 4 : 1);                // rows per block
+    hipLaunchKernelGGL((disc_conv_pool_bwd_x_small_kernel<TA, 32, 8>), dim3((unsigned)cdiv(MR, rpb)), dim3(256), 0, stream,
+                       (const float*)ws->dpooled, (const TA*)st->pooled, (const uint8_t*)st->argmax, c.cm, c.L, c.De, c.R,
+                       (TA*)ws->demb, (int)MR, rpb);
+  } else {
+    hipLaunchKernelGGL((disc_conv_pool_bwd_x_kernel<TA>), dim3((unsigned)MR), dim3(256), bwd_x_lds, stream,
+                       (const float*)ws->dpooled, (const TA*)st->pooled, (const uint8_t*)st->argmax, c.cm, c.L, c.De, c.R, (TA*)ws->demb);
+  }
   GIC_CHECK_LAUNCH("disc_conv_pool_bwd_x");
   // 5. embedding backward
   if (G) {
