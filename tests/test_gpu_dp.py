@@ -1,0 +1,36 @@
+"""Data parallelism on the GPU path, rehearsed on ONE card: two ranks share cuda:0 and all-reduce through gloo
+(RCCL refuses two ranks on one device; GIC_DIST_BACKEND=gloo swaps the backend, everything else is the production path:
+DistInfo.from_env, shard_rows, broadcast of the replicas, GradReducer inside FusedAdvStep, clip after the all-reduce).
+Two steps of 2 x 4 captions must reproduce the single-process run on the 8 captions."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_reproduce_the_single_process_step(tmp_path):
+    worker = os.path.join(ROOT, "tests", "dp_gpu_worker.py")
+    env = dict(os.environ, GIC_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    single = str(tmp_path / "single_%d.pt")
+    r = subprocess.run([sys.executable, worker, single], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    multi = str(tmp_path / "multi_%d.pt")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", worker, multi], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    one = torch.load(single % 0)
+    r0, r1 = torch.load(multi % 0), torch.load(multi % 1)
+    assert one["world"] == 1 and r0["world"] == 2
+    # replicas stay identical
+    assert torch.equal(r0["gen"], r1["gen"]) and torch.equal(r0["disc"], r1["disc"])
+    # the mean of the two shard losses is the global-batch loss; weights after two clip+Adam steps match the single process
+    torch.testing.assert_close((r0["losses"] + r1["losses"]) / 2, one["losses"], rtol=1e-5, atol=1e-7)
+    assert r0["d_norm"] == pytest.approx(one["d_norm"], rel=1e-4)      # norm of the AVERAGED gradient, not of a shard's
+    torch.testing.assert_close(r0["disc"], one["disc"], rtol=1e-4, atol=2e-6)
+    torch.testing.assert_close(r0["gen"], one["gen"], rtol=1e-4, atol=2e-6)
