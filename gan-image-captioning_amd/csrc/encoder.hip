@@ -181,15 +181,24 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const TA* __restri
   }
 }
 
-// ---- global average pool: x [N, HW, C] -> out [N, C] (act) ; one thread per (n, c)
+// ---- global average pool: x [N, HW, C] -> out [N, C] (act) ; one thread per (n, c), 7 loads in flight
 template <typename TA>
 __global__ void avgpool_kernel(const TA* __restrict__ x, TA* __restrict__ out, int N, int HW, int C) {
   const long total = (long)N * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const long n = i / C;
+    const TA* xp = x + n * HW * C + c;
     float s = 0.f;
-    for (int p = 0; p < HW; ++p) s += to_f32<TA>(x[(n * HW + p) * C + c]);
+    int p = 0;
+    for (; p + 7 <= HW; p += 7) {                    // sequential summation order kept (parity), loads issued together
+      float v[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) v[q] = to_f32<TA>(xp[(long)(p + q) * C]);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) s += v[q];
+    }
+    for (; p < HW; ++p) s += to_f32<TA>(xp[(long)p * C]);
     out[i] = from_f32<TA>(s / (float)HW);
   }
 }
@@ -210,7 +219,7 @@ __global__ void bn_running_update_kernel(const gic_bn_running_desc* __restrict__
   const gic_bn_running_desc d = table[l];
   const float inv = 1.f / d.count;
   const float unbias = d.count > 1.f ? d.count / (d.count - 1.f) : 1.f;
-  for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+  for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < d.C; c += blockDim.x * gridDim.y) {   // gridDim.y channel slabs: one round trip
     float s1 = 0.f, s2 = 0.f;
     for (int r = 0; r < d.nrep; ++r) { s1 += d.stats[(long)r * 2 * d.C + c]; s2 += d.stats[(long)r * 2 * d.C + d.C + c]; }
     const float mean = s1 * inv;
@@ -417,7 +426,7 @@ int gic_fold_stats(const float* stats, int nrep, float* out, int n, void* stream
 
 int gic_bn_running_update(const gic_bn_running_desc* table_dev, int nlayers, void* stream) {
   GIC_CHECK_ARG(table_dev && nlayers > 0, "bn_running_update: bad argument");
-  hipLaunchKernelGGL(bn_running_update_kernel, dim3(nlayers), dim3(256), 0, (hipStream_t)stream, table_dev, nlayers);
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(nlayers, 8), dim3(256), 0, (hipStream_t)stream, table_dev, nlayers);
   GIC_CHECK_LAUNCH("bn_running_update");
   return GIC_OK;
 }
