@@ -113,7 +113,6 @@ _SIGNATURES = {
     "gic_bn_act": (C.c_int, [c_void_p] * 12 + [C.c_int, C.c_float, C.c_int, c_void_p, C.c_int, C.c_int64, C.c_int, c_void_p]),
     "gic_bn_relu_maxpool": (C.c_int, [c_void_p] * 6 + [C.c_int, C.c_float, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),
     "gic_avgpool": (C.c_int, [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),
-    "gic_fold_stats": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, c_void_p]),
     "gic_bn_running_update": (C.c_int, [c_void_p, C.c_int, c_void_p]),
     "gic_bn1d_fwd": (C.c_int, [c_void_p] * 5 + [C.c_int, C.c_float, C.c_float, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, c_void_p]),
     "gic_bn1d_bwd": (C.c_int, [c_void_p] * 4 + [C.c_int, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, c_void_p]),

@@ -203,15 +203,6 @@ __global__ void avgpool_kernel(const TA* __restrict__ x, TA* __restrict__ out, i
   }
 }
 
-// ---- fold the statistics replicas of one layer: out[i] = sum_r stats[r][i]  (i < n = 2C)
-__global__ void fold_stats_kernel(const float* __restrict__ stats, int nrep, float* __restrict__ out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int r = 0; r < nrep; ++r) s += stats[(long)r * n + i];
-  out[i] = s;
-}
-
 // ---- running statistics of every BatchNorm2d of the trunk in one launch (table built once by the host)
 __global__ void bn_running_update_kernel(const gic_bn_running_desc* __restrict__ table, int nlayers) {
   const int l = blockIdx.x;
@@ -414,13 +405,6 @@ int gic_avgpool(const void* x, void* out, int dtype, int N, int HW, int C, void*
   else
     hipLaunchKernelGGL((avgpool_kernel<bf16_t>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, N, HW, C);
   GIC_CHECK_LAUNCH("avgpool");
-  return GIC_OK;
-}
-
-int gic_fold_stats(const float* stats, int nrep, float* out, int n, void* stream) {
-  GIC_CHECK_ARG(stats && out && nrep >= 1 && n > 0, "fold_stats: bad argument");
-  hipLaunchKernelGGL(fold_stats_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, stats, nrep, out, n);
-  GIC_CHECK_LAUNCH("fold_stats");
   return GIC_OK;
 }
 

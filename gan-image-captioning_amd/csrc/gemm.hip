@@ -1,22 +1,16 @@
-// MFMA GEMM family for gfx950 (MI355X).  One templated kernel covers every dense
-// contraction on the hot path (LSTM gates, vocab projection, discriminator
-// embedding / highway / head, all dgrad and wgrad products, the encoder head):
+// MFMA GEMM family for gfx950 (MI355X): every dense contraction on the hot path (trunk convolutions as implicit GEMM, LSTM
+// gates, vocab projection, discriminator embedding / highway / head, all dgrad and wgrad products, the encoder head).
 //
-//  * 16x16 MFMA tiles: v_mfma_f32_16x16x32_bf16 (bf16 in, f32 acc) or
-//    v_mfma_f32_16x16x4_f32 (exact f32 fma chain; parity mode).
-//  * 256 threads = 4 waves (2x2), block tile 128x128 or 64x64, 128 bytes of K per
-//    LDS row (+16 B pad so a 16-lane ds_read_b128 group hits 64 distinct banks).
-//  * operands may be k-contiguous (LDS image [row][k], ds_read_b128 fragments) or
-//    m/n-contiguous (LDS image [k][row]; bf16 fragments come out of
-//    ds_read_b64_tr_b16, the gfx950 transposing LDS read) so dgrad / wgrad need
-//    no transposed copies in HBM.
-//  * global -> VGPR -> LDS staging, two LDS buffers: tile k+1's global loads are issued
-//    before tile k's MFMAs and written to the other buffer after them; one barrier per
-//    K tile.  16-byte loads/stores when shapes allow, scalar fallback otherwise.
-//  * split-K over gridDim.y (f32 atomic accumulate) for the skinny recurrent products
-//    (M = batch) that would otherwise occupy a handful of CUs.
-//  * XCD-aware block -> tile map: each of the 8 XCDs owns a contiguous run of
-//    tiles that share B (weight) panels in its private L2.
+// Two kernels:
+//   gemm_kernel   4 waves (2x2), 128x128 or 64x64 tile.  Any operand layout (k-contiguous: LDS image [row][k], ds_read_b128
+//                 fragments; m/n-contiguous: LDS image [k][row], bf16 fragments out of ds_read_b64_tr_b16, so dgrad / wgrad
+//                 need no transposed copies in HBM), bf16 (v_mfma_f32_16x16x32_bf16) or exact f32 (v_mfma_f32_16x16x4_f32,
+//                 parity mode), register-staged double buffer or 3-stage LDS-DMA ring, split-K over gridDim.y (f32 atomics)
+//                 for skinny / deep-K products, highway epilogue, 16-byte accesses when shapes allow, scalar fallback.
+//   tile8_kernel  8 waves (4x2), 128x128 or 128x64 tile, bf16 k-contiguous operands only: buffer-descriptor LDS-DMA ring of 1 /
+//                 2 / 4 stages.  Every trunk convolution in bf16 mode and the wide plain / highway products.  See its header.
+// Both: XCD-aware block -> tile map (each of the 8 XCDs owns a contiguous run of tiles that share B panels in its L2), C tile
+// staged through LDS for 16-byte row stores, BatchNorm column sums folded across the block in the epilogue.
 #include "gemm.h"
 
 #include <stdlib.h>

@@ -166,7 +166,6 @@ class FusedAdvStep:
         main.wait_event(ev_gprep)
         probs, ids, dst = self.dec.sample_fwd(gparams, feats, L, T, False, noise_u, seed, state=buf["dec_state"],
                                               out=buf["probs"], ids=buf["ids"])
-        ev_probs = main.record_event()
         self._mark("roll-out done", main)
 
         # ---- D(fake), D(gen) (training.py:163-164): one pass up to the highway layer, two dropout draws + heads

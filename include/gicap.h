@@ -245,9 +245,6 @@ int gic_bn_relu_maxpool(const void* y, const float* stats, const float* gamma, c
                         void* stream);
 /* Global average pool: x act [N,HW,C] -> out act [N,C]. */
 int gic_avgpool(const void* x, void* out, int dtype, int N, int HW, int C, void* stream);
-/* out[i] = sum over the nrep replicas of stats[r][i], i < n (= 2*C): folds one layer's BatchNorm sums once so that the
- * element-wise consumers read them with stats_nrep = 1. */
-int gic_fold_stats(const float* stats, int nrep, float* out, int n, void* stream);
 /* Running mean/var of every trunk BatchNorm2d in one launch; `table_dev` is a DEVICE array built once by the caller. */
 typedef struct gic_bn_running_desc {
   const float* stats;      /* [nrep][2C] raw sums of this step */
