@@ -214,12 +214,15 @@ class FusedAdvStep:
         if self.reducer is not None:
             self.reducer.start(self.disc_arena.grad)
         self._mark("D path done", main)
-        main.wait_event(ev_dgen)
+        main.wait_event(ev_dgen)                 # D's weights are no longer read by the G path
+        if self.reducer is None and opt_step:
+            self.disc_opt.step()                 # D's clip + Adam runs under the rest of the G path
         main.wait_event(ev_g)
         if self.reducer is not None:
             self.reducer.wait_all()
+            if opt_step:
+                self.disc_opt.step()
         if opt_step:
-            self.disc_opt.step()
             self.gen_opt.step()
         self._mark("optimizers done", main)
         return out
