@@ -97,7 +97,7 @@ _SIGNATURES = {
                                          c_void_p, C.c_uint64, C.c_float, C.c_int, c_void_p, c_void_p, c_void_p]),
     "gic_decoder_sample_bwd": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), _P(DecoderState),
                                          _P(DecoderBwdWs), c_void_p, c_void_p, c_void_p, C.c_float, C.c_int,
-                                         _P(DecoderGrads), c_void_p]),
+                                         _P(DecoderGrads), C.c_int, c_void_p]),
     "gic_embedding_fwd": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, c_void_p]),
     "gic_embedding_bwd": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int, c_void_p]),
     "gic_disc_prepare": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), c_void_p]),

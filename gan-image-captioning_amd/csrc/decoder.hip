@@ -336,20 +336,19 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
 template <typename TA>
 int sample_bwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_shadow* S, const gic_decoder_state* st,
                  const gic_decoder_bwd_ws* ws, const void* probs, const int64_t* ids, const void* d_out,
-                 float temperature, int pretrain, const gic_decoder_grads* G, hipStream_t stream) {
+                 float temperature, int pretrain, const gic_decoder_grads* G, int phases, hipStream_t stream) {
   const int B = c.B, L = c.L, V = c.V, E = c.E, H = c.H, NL = c.NL;
   const long BL = (long)B * L;
   const int pw_grid = cdiv((long)B * H, 256);
   // 1. d_logits [B,L,V]
-  const void* dlog = d_out;
-  if (!pretrain) {
+  const void* dlog = pretrain ? d_out : (const void*)ws->dlogits;
+  if (!pretrain && (phases & GIC_DECODER_BWD_OUTPUT)) {
     hipLaunchKernelGGL((softmax_bwd_kernel<TA>), dim3((unsigned)BL), dim3(256), 0, stream, (const TA*)probs,
                        (const TA*)d_out, (TA*)ws->dlogits, temperature, V);
     GIC_CHECK_LAUNCH("softmax_bwd");
-    dlog = ws->dlogits;
   }
   // 2. d_hout = d_logits W_out ; dW_out = d_logits^T hout ; db_out = colsum(d_logits)
-  {
+  if (phases & GIC_DECODER_BWD_OUTPUT) {
     GemmDesc g;
     g.A = dlog; g.lda = V; g.a_kc = 1; g.B = S->wout; g.ldb = H; g.b_kc = 0; g.C = ws->dhout; g.ldc = H;
     g.M = (int)BL; g.N = H; g.K = V; g.in_dtype = c.dt; g.out_dtype = DT_F32;
@@ -360,6 +359,7 @@ int sample_bwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
     GIC_PROPAGATE(gemm(w, stream));
     GIC_PROPAGATE(colsum(dlog, c.dt, V, BL, V, G->b_out, nullptr, 0, stream));
   }
+  if (!(phases & GIC_DECODER_BWD_RECURRENT)) return GIC_OK;
   // 3. BPTT
   for (int l = 0; l < NL; ++l) {
     GIC_PROPAGATE(fill_zero(ws->dc[l], (size_t)B * H * sizeof(float), stream));
@@ -469,7 +469,7 @@ int gic_decoder_sample_fwd(const gic_decoder_dims* dims, const gic_decoder_param
 int gic_decoder_sample_bwd(const gic_decoder_dims* dims, const gic_decoder_params* P, const gic_decoder_shadow* S,
                            const gic_decoder_state* st, const gic_decoder_bwd_ws* ws, const void* probs,
                            const int64_t* ids, const void* d_out, float temperature, int pretrain,
-                           const gic_decoder_grads* G, void* stream_) {
+                           const gic_decoder_grads* G, int phases, void* stream_) {
   Ctx c;
   GIC_PROPAGATE(check_dims(dims, c));
   GIC_CHECK_ARG(P && S && st && ws && probs && ids && d_out && G, "decoder_sample_bwd: null argument");
@@ -478,11 +478,12 @@ int gic_decoder_sample_bwd(const gic_decoder_dims* dims, const gic_decoder_param
     GIC_CHECK_ARG(ws->dgates[l] && ws->dxh[l] && ws->dc[l] && G->w_ih[l] && G->w_hh[l] && G->b_ih[l] && G->b_hh[l],
                   "decoder_sample_bwd: null layer %d buffer", l);
   hipStream_t stream = (hipStream_t)stream_;
+  GIC_CHECK_ARG(phases >= 1 && phases <= GIC_DECODER_BWD_ALL, "decoder_sample_bwd: phases must be 1, 2 or 3");
   int s = (c.dt == DT_F32)
-              ? sample_bwd_t<float>(c, P, S, st, ws, probs, ids, d_out, temperature, pretrain, G, stream)
-              : sample_bwd_t<bf16_t>(c, P, S, st, ws, probs, ids, d_out, temperature, pretrain, G, stream);
+              ? sample_bwd_t<float>(c, P, S, st, ws, probs, ids, d_out, temperature, pretrain, G, phases, stream)
+              : sample_bwd_t<bf16_t>(c, P, S, st, ws, probs, ids, d_out, temperature, pretrain, G, phases, stream);
   GIC_PROPAGATE(s);
-  if (c.L > 1) {
+  if (c.L > 1 && (phases & GIC_DECODER_BWD_RECURRENT)) {
     const long total = (long)(c.L - 1) * c.B * c.E;
     const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     hipLaunchKernelGGL(embed_scatter_time_kernel, dim3(grid), dim3(256), 0, stream, (const float*)ws->dxh[0], c.ldx(0), ids,

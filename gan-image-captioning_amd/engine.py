@@ -266,7 +266,8 @@ class DecoderEngine:
         return out, ids, st
 
     def sample_bwd(self, params, st, out: torch.Tensor, ids: torch.Tensor, d_out: torch.Tensor, temperature: float,
-                   pretrain: bool = False, ws=None, grads=None) -> List[torch.Tensor]:
+                   pretrain: bool = False, ws=None, grads=None, phases: int = 3) -> List[torch.Tensor]:
+        """phases: 1 = output layer only (w_out / b_out gradients complete), 2 = recurrent part, 3 = both (gicap.h)."""
         B, Lc = ids.shape
         dev = out.device
         if d_out.dtype != self.act:
@@ -284,7 +285,7 @@ class DecoderEngine:
         L.check(L.load().gic_decoder_sample_bwd(
             C.byref(d), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
             C.byref(w), ptr(out), ptr(ids), ptr(d_out), float(temperature), int(bool(pretrain)),
-            C.byref(self._pstruct(grads[:-1], L.DecoderGrads, grads[-1])), stream_ptr()), "gic_decoder_sample_bwd")
+            C.byref(self._pstruct(grads[:-1], L.DecoderGrads, grads[-1])), int(phases), stream_ptr()), "gic_decoder_sample_bwd")
         return grads
 
     def _cast_like(self, t: torch.Tensor) -> torch.Tensor:

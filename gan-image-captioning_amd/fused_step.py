@@ -64,6 +64,13 @@ class FusedAdvStep:
             self._buf[key]["st_gen"] = den.shared_state(self._buf[key]["st_fake"], B, L, dev)
         return self._buf[key]
 
+    def _early_bucket(self):
+        """Arena span of decoder.linear's weight and bias (None if they are not adjacent in the arena)."""
+        if not hasattr(self, "_early"):
+            lin = self.gen.decoder.linear
+            self._early = self.gen_arena.span([lin.weight, lin.bias])
+        return self._early
+
     def _mark(self, name: str, stream) -> None:
         """Phase marker for tools/step_timeline.py (``self.trace`` is a list while tracing, else None)."""
         if self.trace is not None:
@@ -194,14 +201,22 @@ class FusedAdvStep:
                              ws=buf["disc_ws_gen"], d_inp=buf["d_probs"])
                 ev_dgen = s_gen.record_event()                     # D's weights are free to change from here on
                 self._mark("D(gen) input-grad done [s_gen]", s_gen)
-                self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"],
-                                    grads=g_grads + [buf["d_feat"]])
+                early = self._early_bucket() if self.reducer is not None else None
+                if early is None:
+                    self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"],
+                                        grads=g_grads + [buf["d_feat"]])
+                else:
+                    # data parallel: the vocabulary projection's gradient (40 % of G's arena) is complete before BPTT starts;
+                    # its all-reduce runs under BPTT and the weight-gradient products instead of after them
+                    self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"],
+                                        grads=g_grads + [buf["d_feat"]], phases=1)
+                    self.reducer.start(self.gen_arena.grad[early[0]:early[1]])
+                    self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"],
+                                        grads=g_grads + [buf["d_feat"]], phases=2)
                 if self.cgan:
                     gen.encoder.backward_fused(buf["d_feat"])
                 else:   # features = embed(<S>) broadcast: fold d_features into row 1 of the embedding gradient
                     engine.embedding_bwd(buf["d_feat"], buf["ones"], self.dec.V, d_weight=g_grads[0], zero_first=False)
-            if self.reducer is not None:
-                self.reducer.start(self.gen_arena.grad)
             ev_g = s_gen.record_event()
             self._mark("G path done [s_gen]", s_gen)
 
@@ -212,16 +227,27 @@ class FusedAdvStep:
         self.den.bwd(dparams, buf["st_fake"], probs, None, d_train, lgrads["dd_fake"], True, False,
                      grads=d_grads, accumulate=True, ws=buf["disc_ws"])
         if self.reducer is not None:
-            self.reducer.start(self.disc_arena.grad)
+            # collectives run one after the other on the reducer's stream, in the order they become ready:
+            # G's early bucket (above), D's arena (now), the rest of G's arena (when the G path is through)
+            ev_dred = self.reducer.start(self.disc_arena.grad)
+            with torch.cuda.stream(s_gen):
+                early = self._early_bucket() if a.adv_loss_type != "rsgan" else None
+                if early is None:
+                    self.reducer.start(self.gen_arena.grad)
+                else:
+                    if early[0] > 0:
+                        self.reducer.start(self.gen_arena.grad[:early[0]])
+                    if early[1] < self.gen_arena.numel:
+                        self.reducer.start(self.gen_arena.grad[early[1]:])
         self._mark("D path done", main)
         main.wait_event(ev_dgen)                 # D's weights are no longer read by the G path
-        if self.reducer is None and opt_step:
+        if self.reducer is not None:
+            self.reducer.wait(ev_dred)
+        if opt_step:
             self.disc_opt.step()                 # D's clip + Adam runs under the rest of the G path
         main.wait_event(ev_g)
         if self.reducer is not None:
             self.reducer.wait_all()
-            if opt_step:
-                self.disc_opt.step()
         if opt_step:
             self.gen_opt.step()
         self._mark("optimizers done", main)

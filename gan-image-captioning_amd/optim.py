@@ -41,6 +41,15 @@ class ParamArena:
                 p.grad = self.grad[o:o + n].view(p.shape)
         engine.bump_param_epoch()
 
+    def span(self, params) -> Optional[tuple]:
+        """(start, end) of the arena slots of ``params`` if they are one contiguous run (in any order), else None."""
+        want = {id(p) for p in params}
+        idx = sorted(i for i, p in enumerate(self.params) if id(p) in want)
+        if len(idx) != len(want) or not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            return None
+        end = self.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.params) else self.numel
+        return self.offsets[idx[0]], end
+
     def grad_views(self) -> List[torch.Tensor]:
         return [self.grad[o:o + n].view(p.shape) for p, o, n in zip(self.params, self.offsets, self.sizes)]
 

@@ -78,13 +78,14 @@ class GradReducer:
         self._side: Optional[torch.cuda.Stream] = None
         self._pending: List[torch.cuda.Event] = []
 
-    def start(self, flat: torch.Tensor) -> None:
+    def start(self, flat: torch.Tensor):
+        """Returns the collective's completion event (None when it ran synchronously) for ``wait``."""
         if self.info.world_size <= 1:
-            return
+            return None
         if not flat.is_cuda or dist.get_backend() == "gloo":      # gloo has no AVG; on device tensors it stages through the host
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             flat.mul_(1.0 / self.info.world_size)
-            return
+            return None
         if self._side is None:
             self._side = torch.cuda.Stream(device=flat.device)
         ready = torch.cuda.Event()
@@ -96,6 +97,14 @@ class GradReducer:
             done.record(self._side)
         flat.record_stream(self._side)
         self._pending.append(done)
+        return done
+
+    def wait(self, done) -> None:
+        """Make the current stream wait for ONE collective (the others stay pending)."""
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
+            if done in self._pending:
+                self._pending.remove(done)
 
     def wait_all(self) -> None:
         for ev in self._pending:

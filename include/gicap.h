@@ -129,12 +129,19 @@ int gic_decoder_sample_fwd(const gic_decoder_dims* dims, const gic_decoder_param
                            const float* features, const float* noise_u, uint64_t seed, float temperature,
                            int pretrain, void* out, int64_t* ids, void* stream);
 
-/* d_out: act [B,L,V] gradient w.r.t. `out`; probs = the forward's `out`. */
+/* d_out: act [B,L,V] gradient w.r.t. `out`; probs = the forward's `out`.
+ * phases (bit mask; GIC_DECODER_BWD_ALL = both, in this order):
+ *   GIC_DECODER_BWD_OUTPUT     softmax/Gumbel backward, d_hout, and the COMPLETE gradients of the vocabulary projection
+ *                              (grads->w_out, grads->b_out): a data-parallel caller can start all-reducing them here
+ *   GIC_DECODER_BWD_RECURRENT  BPTT, LSTM weight gradients, d_features, embedding gradient */
+#define GIC_DECODER_BWD_OUTPUT 1
+#define GIC_DECODER_BWD_RECURRENT 2
+#define GIC_DECODER_BWD_ALL 3
 int gic_decoder_sample_bwd(const gic_decoder_dims* dims, const gic_decoder_params* params,
                            const gic_decoder_shadow* shadow, const gic_decoder_state* state,
                            const gic_decoder_bwd_ws* ws, const void* probs, const int64_t* ids,
                            const void* d_out, float temperature, int pretrain,
-                           const gic_decoder_grads* grads, void* stream);
+                           const gic_decoder_grads* grads, int phases, void* stream);
 
 /* nn.Embedding used as a callable (training.py:68,147): out[i,:] = weight[ids[i],:] and its scatter-add. */
 int gic_embedding_fwd(const float* weight, const int64_t* ids, float* out, int64_t n, int32_t V, int32_t E, void* stream);
