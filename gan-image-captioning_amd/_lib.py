@@ -109,6 +109,8 @@ _SIGNATURES = {
                                C.c_int64, c_void_p, C.c_int, c_void_p, _P(DiscGrads), C.c_int, c_void_p, C.c_int64, c_void_p]),
     "gic_pack_image": (C.c_int, [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),
     "gic_repack_conv_weight": (C.c_int, [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),
+    "gic_conv2d_bn_in": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_float, c_void_p, c_void_p, c_void_p, C.c_int,
+                         C.c_int] + [C.c_int] * 9 + [c_void_p]),
     "gic_conv2d": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int] + [C.c_int] * 9 + [c_void_p]),
     "gic_bn_act": (C.c_int, [c_void_p] * 12 + [C.c_int, C.c_float, C.c_int, c_void_p, C.c_int, C.c_int64, C.c_int, c_void_p]),
     "gic_bn_relu_maxpool": (C.c_int, [c_void_p] * 6 + [C.c_int, C.c_float, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),
@@ -158,6 +160,9 @@ def load() -> C.CDLL:
         raise GicError(f"ABI version mismatch: library {lib.gic_abi_version()}, binding 1")
     _lib = lib
     return lib
+
+
+ERR_UNSUPPORTED = -2          # enum gic_status GIC_STATUS_UNSUPPORTED
 
 
 def check(status: int, what: str = "") -> None:

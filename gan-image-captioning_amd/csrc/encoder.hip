@@ -361,6 +361,27 @@ int gic_conv2d(const void* in, const void* w, void* out, float* stats, int stats
   return gemm(g, (hipStream_t)stream);
 }
 
+int gic_conv2d_bn_in(const void* in, const float* in_stats, int in_nrep, const float* in_gamma, const float* in_beta, float in_count,
+                     const void* w, void* out, float* stats, int stats_nrep, int dtype, int N, int H, int W, int Cin, int Cout, int KH,
+                     int KW, int stride, int pad, void* stream) {
+  GIC_CHECK_ARG(in && in_stats && in_gamma && in_beta && w && out && stats && in_count > 0 && in_nrep >= 1, "conv2d_bn_in: bad argument");
+  GIC_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "conv2d_bn_in: bad dims");
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  GIC_CHECK_ARG(Ho > 0 && Wo > 0, "conv2d_bn_in: empty output");
+  if (dtype != DT_BF16) return GIC_ERR_UNSUPPORTED;
+  GemmDesc g;
+  g.A = in; g.B = w; g.C = out;
+  g.M = N * Ho * Wo; g.N = Cout; g.K = KH * KW * Cin;
+  g.lda = Cin; g.ldb = g.K; g.ldc = Cout;
+  g.in_dtype = dtype; g.out_dtype = dtype;
+  g.conv = 1; g.cH = H; g.cW = W; g.cCin = Cin; g.cHo = Ho; g.cWo = Wo; g.cKH = KH; g.cKW = KW; g.cStride = stride; g.cPad = pad;
+  g.epi = EPI_BNSTATS;
+  g.stats = stats;
+  g.stats_nrep = stats_nrep < 1 ? 1 : stats_nrep;
+  g.in_stats = in_stats; g.in_nrep = in_nrep; g.in_gamma = in_gamma; g.in_beta = in_beta; g.in_inv_count = 1.f / in_count;
+  return gemm(g, (hipStream_t)stream);
+}
+
 int gic_bn_act(const void* y, const float* stats, const float* gamma, const float* beta, const float* run_mean, const float* run_var,
                const void* res, const float* res_stats, const float* res_gamma, const float* res_beta, const float* res_run_mean,
                const float* res_run_var, int stats_nrep, float count, int relu, void* out, int dtype, int64_t rows, int C, void* stream) {

@@ -43,6 +43,14 @@ struct GemmDesc {
   // ---- EPI_BNSTATS: C = result (+bias) and stats[n] += sum_m v, stats[N+n] += sum_m v^2 (f32 atomics)
   float* stats = nullptr;   // [stats_nrep][2N]; block b adds into replica b % stats_nrep (readers sum the replicas)
   int stats_nrep = 1;
+  // ---- A-side BatchNorm + ReLU (tile8 convolutions with Cin % 8 == 0, Cin <= 1024): the input activation is read as
+  //      relu(scale[c] * x + shift[c]) (zero padding applied AFTER it, as the reference pads the normalised tensor) with
+  //      scale / shift from the producer's batch statistics in_stats [in_nrep][2 Cin] (sum, sum of squares over
+  //      in_inv_count^-1 rows), in_gamma, in_beta.  The producer's raw output is consumed directly: its separate
+  //      normalisation pass (and the normalised tensor) disappear.
+  const float* in_stats = nullptr; int in_nrep = 1;
+  const float* in_gamma = nullptr; const float* in_beta = nullptr;
+  float in_inv_count = 0.f;
   int dbg = 0;              // phase-ablation knob, honoured only by -DGIC_STAMPS tool builds
 };
 

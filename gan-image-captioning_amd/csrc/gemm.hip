@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
 //     zero without touching memory -- no 64-bit address math, no branches, no zero page;
 //   * every iteration issues exactly NL DMAs, so the counted s_waitcnt is a constant and the loop body is branch-free.
 // Waves are 4 (M) x 2 (N): a wave owns 32 x BN/2 of the tile.  LDS image, swizzle and C/D layout as in the kernel above.
-template <typename TO, int BN, int EPI, bool CONV, int NS>
+template <typename TO, int BN, int EPI, bool CONV, int NS, bool ABN = false>
 __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsigned a_bytes, const unsigned b_bytes) {
   constexpr int BM = 128, BK = 64, NT = 512;
   constexpr int TM = 2, TN = BN / 32;
@@ -535,7 +535,9 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int OSZ = sizeof(TO), OVE = 16 / OSZ, SC = BN * OSZ + 16;
   constexpr int EPI_BYTES = BM * SC + 8 * (BN / 2) * 2 * 4;
-  constexpr int SMEM_BYTES = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
+  constexpr int RING_BYTES = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
+  constexpr int ABN_MAXK = 1024;                              // A-side BatchNorm: [scale, shift] per input channel behind the ring
+  constexpr int SMEM_BYTES = RING_BYTES + (ABN ? ABN_MAXK * 8 : 0);
   constexpr unsigned OOB = 0x80000000u;                       // >= any extent this kernel is launched with
   static_assert(CB >= 1 && SMEM_BYTES <= 160 * 1024, "tile8 LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
@@ -626,6 +628,52 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
     }
   };
 
+  // ---- A-side BatchNorm + ReLU: per-channel [scale, shift] from the producer's sums, then each thread normalises the chunks it
+  // DMA'd itself (its own vmcnt wait covers them) in LDS before the barrier publishes the stage.
+  float* coef = (float*)(smem + RING_BYTES);
+  if constexpr (ABN) {
+    const int Cn = CONV ? d.cCin : K;                          // channels of the normalised operand
+    for (int c = tid; c < ABN_MAXK; c += NT) {
+      float sc = 0.f, sh = 0.f;
+      if (c < Cn) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < d.in_nrep; ++r) { s1 += d.in_stats[(long)r * 2 * Cn + c]; s2 += d.in_stats[(long)r * 2 * Cn + Cn + c]; }
+        const float mean = s1 * d.in_inv_count;
+        const float var = fmaxf(s2 * d.in_inv_count - mean * mean, 0.f);
+        sc = d.in_gamma[c] * rsqrtf(var + 1e-5f);              // kBnEps of encoder.hip (nn.BatchNorm2d default)
+        sh = d.in_beta[c] - mean * sc;
+      }
+      coef[2 * c] = sc; coef[2 * c + 1] = sh;
+    }
+    __syncthreads();
+  }
+  auto abn = [&](int kt, int st) {
+    if constexpr (ABN) {
+      const int k = kt * BK + kc;
+      if (k < K) {
+        // channel and tap of this thread's chunks (all CA of them share k): a 16-byte chunk never straddles a tap (Cin % 8 == 0)
+        const int ch = CONV ? k % d.cCin : k;
+        const int tap = CONV ? k / d.cCin : 0;
+        const int ts = tap % (CONV ? d.cKW : 1), tr = tap / (CONV ? d.cKW : 1);
+        const float4* cp = (const float4*)(coef + 2 * ch);
+        const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+        const float scl[8] = {c0.x, c0.z, c1.x, c1.z, c2.x, c2.z, c3.x, c3.z};
+        const float sft[8] = {c0.y, c0.w, c1.y, c1.w, c2.y, c2.w, c3.y, c3.w};
+#pragma unroll
+        for (int i = 0; i < CA; ++i) {
+          // padding taps and rows past M were zero-filled by the DMA and stay zero (the reference pads the NORMALISED tensor)
+          const bool ok = CONV ? ((unsigned)(a_hi0[i] + tr) < (unsigned)d.cH & (unsigned)(a_wi0[i] + ts) < (unsigned)d.cW) : a_ok[i];
+          if (!ok) continue;
+          bf16x8* p = (bf16x8*)(smem + st * STAGE + i * (NT * 16) + tid * 16);
+          bf16x8 v = *p;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bf16_t)fmaxf((float)v[e] * scl[e] + sft[e], 0.f);
+          *p = v;
+        }
+      }
+    }
+  };
+
   f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -692,6 +740,7 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
       if (kt) __builtin_amdgcn_s_barrier();            // every wave is done reading the previous tile
       issue(kt, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      abn(kt, 0);
       __builtin_amdgcn_s_barrier();
       compute(0);
     }
@@ -701,6 +750,7 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
     int st = 0;
     for (int kt = 0; kt < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      abn(kt, st);
       __builtin_amdgcn_s_barrier();                      // stage kt published; every wave is done reading stage kt-1
       if (kt == 0) STAMP(2);
       if (!(DBG & 1)) issue(kt + 1, st ^ 1);
@@ -720,6 +770,7 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
       // stage kt has landed once all but this wave's newest (NS-2) tiles are done.  This wave's reads of stage kt-1 (their
       // data is needed below anyway) must have returned before the barrier lets anyone refill that stage.
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NS >= 2 ? (NS - 2) * NL : 0) : "memory");
+      abn(kt, st);
       __builtin_amdgcn_s_barrier();
       if (kt == 0) STAMP(2);
       if (!(DBG & 2)) {
@@ -868,6 +919,26 @@ bool try_tile8(const GemmDesc& d, hipStream_t stream) {
   const unsigned ab = (unsigned)(a_elems * 2), bb = (unsigned)(b_elems * 2);
   // deep ring (4 stages, 128 KB: one block per CU) when the grid is about one block per CU; with several blocks per CU a
   // 2-stage ring (64 KB) lets two blocks share the CU so one block's epilogue runs under the other's K loop
+  if constexpr (EPI == EPI_BNSTATS && CONV) {
+    if (d.in_stats) {      // A-side BatchNorm + ReLU: whole 16-byte chunks per tap, channels within the LDS table
+      if (d.cCin % 8 || d.cCin > 1024 || !d.in_gamma || !d.in_beta || d.in_inv_count <= 0.f) return false;
+      const int nk = cdiv(d.K, 64);
+      const bool n128 = d.N >= 128 && big_tiles >= big_min;
+      const long tiles = n128 ? big_tiles : (long)cdiv(d.M, 128) * cdiv(d.N, 64);
+      const dim3 grid((unsigned)tiles), block(512);
+      if (nk <= 4 && tiles > 512) {
+        if (n128) hipLaunchKernelGGL((tile8_kernel<TO, 128, EPI, CONV, 1, true>), grid, block, 0, stream, d, ab, bb);
+        else hipLaunchKernelGGL((tile8_kernel<TO, 64, EPI, CONV, 1, true>), grid, block, 0, stream, d, ab, bb);
+      } else if (tiles > 256) {
+        if (n128) hipLaunchKernelGGL((tile8_kernel<TO, 128, EPI, CONV, 2, true>), grid, block, 0, stream, d, ab, bb);
+        else hipLaunchKernelGGL((tile8_kernel<TO, 64, EPI, CONV, 2, true>), grid, block, 0, stream, d, ab, bb);
+      } else {
+        if (n128) hipLaunchKernelGGL((tile8_kernel<TO, 128, EPI, CONV, 4, true>), grid, block, 0, stream, d, ab, bb);
+        else hipLaunchKernelGGL((tile8_kernel<TO, 64, EPI, CONV, 4, true>), grid, block, 0, stream, d, ab, bb);
+      }
+      return true;
+    }
+  }
   static const int ns1_nk = [] { const char* e = getenv("GIC_TILE8_NS1_NK"); return e ? atoi(e) : 4; }();
   const int nk8 = cdiv(d.K, 64);
   if (EPI != EPI_HIGHWAY && nk8 <= ns1_nk && (d.N >= 128 ? big_tiles : (long)cdiv(d.M, 128) * cdiv(d.N, 64)) > 512) {
@@ -976,6 +1047,7 @@ int pick_conv(const GemmDesc& d, hipStream_t stream) {
   if constexpr (sizeof(TI) == 2) {
     if (try_tile8<TO, EPI, true>(d, stream)) { GIC_CHECK_LAUNCH("conv tile8"); return GIC_OK; }
   }
+  if (d.in_stats) return GIC_ERR_UNSUPPORTED;                 // the A-side BatchNorm exists in tile8 only (no message: callers probe)
   const long big_tiles = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
   if (big_tiles >= big_tile_min() && d.N >= 128) return launch<TI, TO, true, true, 128, 128, true, EPI, true>(d, stream);
   return launch<TI, TO, true, true, 64, 64, true, EPI, true>(d, stream);

@@ -28,12 +28,13 @@ def _check(status, what):
 
 
 class _ConvStep:
-    __slots__ = ("conv", "bn", "cin", "cout", "k", "stride", "pad", "stats_off", "w", "name")
+    __slots__ = ("conv", "bn", "cin", "cout", "k", "stride", "pad", "stats_off", "fused_in", "w", "name")
 
     def __init__(self, name, conv, bn):
         self.name, self.conv, self.bn = name, conv, bn
         self.cin, self.cout, self.k, self.stride, self.pad = conv.cin, conv.cout, conv.k, conv.stride, conv.pad
         self.stats_off = 0
+        self.fused_in = None     # None: not probed; True / False: gic_conv2d_bn_in accepted / refused this layer's shapes
         self.w = None
 
 
@@ -62,6 +63,7 @@ class TrunkPlan:
         self._bufs: Dict[Tuple[int, int], dict] = {}
         self._graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
         self._warm: set = set()
+        self.fuse_in = not os.environ.get("GIC_NO_FUSED_BN_IN")
         self._nrep = {}
         self.use_graph = not os.environ.get("GIC_NO_GRAPH")
         self.pending_tracked = 0
@@ -162,6 +164,24 @@ class TrunkPlan:
         _check(L.load().gic_conv2d(ptr(x), ptr(s.w), ptr(y), st, self._nrep[s.name], self.dtype, N, H, W, cin if cin is not None else s.cin, s.cout, s.k,
                                    kw if kw is not None else s.k, s.stride, pad if pad is not None else s.pad, stream_ptr()), "gic_conv2d " + s.name)
 
+    def _bn_relu_conv(self, prev: _ConvStep, y_prev, z_prev, s: _ConvStep, y, stats, training: bool, N, H, W, rows_prev) -> None:
+        """z = relu(bn_prev(y_prev)); y = conv_s(z).  In bf16 training mode the normalisation rides in the convolution's A-operand
+        path (gic_conv2d_bn_in: z_prev is never written); otherwise bn_act + convolution."""
+        if training and self.fuse_in and s.fused_in is not False and self.dtype != L.F32:
+            base = stats.data_ptr()
+            status = L.load().gic_conv2d_bn_in(ptr(y_prev), base + 4 * prev.stats_off, self._nrep[prev.name], ptr(prev.bn.weight.detach()),
+                                               ptr(prev.bn.bias.detach()), float(rows_prev), ptr(s.w), ptr(y), base + 4 * s.stats_off,
+                                               self._nrep[s.name], self.dtype, N, H, W, s.cin, s.cout, s.k, s.k, s.stride, s.pad,
+                                               stream_ptr())
+            if status == L.ERR_UNSUPPORTED:
+                s.fused_in = False
+            else:
+                _check(status, "gic_conv2d_bn_in " + s.name)
+                s.fused_in = True
+                return
+        self._bn_act(prev, y_prev, z_prev, stats, training, rows_prev)
+        self._conv(s, z_prev, y, stats, N, H, W)
+
     def _bn_args(self, s: Optional[_ConvStep], stats: Optional[torch.Tensor], training: bool):
         """(stats, gamma, beta, run_mean, run_var) pointers of one BatchNorm; all None for 'no BN'."""
         if s is None:
@@ -248,10 +268,11 @@ class TrunkPlan:
                 last, ylast = c2, e["y2"]
             else:
                 self._conv(c1, x, e["y1"], stats, N, hin, hin)
+                # measured: riding bn1 into the 3x3 convolution's A path costs more than the bn_act it saves (the tile is rewritten
+                # once per tap); the 1x1 consumer below is where it pays
                 self._bn_act(c1, e["y1"], e["z1"], stats, training, rows[c1.name])
                 self._conv(c2, e["z1"], e["y2"], stats, N, hin, hin)
-                self._bn_act(c2, e["y2"], e["z2"], stats, training, rows[c2.name])
-                self._conv(c3, e["z2"], e["y3"], stats, N, ho, ho)
+                self._bn_relu_conv(c2, e["y2"], e["z2"], c3, e["y3"], stats, training, N, ho, ho, rows[c2.name])
                 last, ylast = c3, e["y3"]
             if ds is not None:
                 self._conv(ds, x, e["yd"], stats, N, hin, hin)
@@ -265,21 +286,32 @@ class TrunkPlan:
             _check(lib.gic_bn_running_update(ptr(b["table"]), len(self.steps), stream_ptr()), "gic_bn_running_update")
 
     # ---------------------------------------------------------------- measurement helper for bench.py
+    def replay(self, s: _ConvStep, xi, yo, stats, N: int, H: int, W: int, kw: dict, prev=None) -> None:
+        """One launch of the step's convolution for layer `s` as the training forward issues it (measurement helper): the
+        A-side-BatchNorm variant where the plan uses it (prev = (producer step, its raw output, its row count)), else gic_conv2d."""
+        if prev is not None and s.fused_in:
+            p, yp, rows_p = prev
+            self._bn_relu_conv(p, yp, None, s, yo, stats, True, N, H, W, rows_p)
+        else:
+            self._conv(s, xi, yo, stats, N, H, W, **kw)
+
     def conv_shapes(self, N: int, S: int):
-        """[(step, input tensor, output tensor, H, W, conv kwargs, macs)] in execution order."""
+        """[(step, input tensor, output tensor, H, W, conv kwargs, macs, prev)] in execution order; prev = (producer step, its raw
+        output, its rows) for the layers whose input BatchNorm can ride in the convolution."""
         b = self._buffers(N, S, self.stem.conv.weight.device)
-        out = [(self.stem, b["xin"], b["y0"], S + 6, S + 6, dict(cin=4, kw=8, pad=0), b["y0"].shape[1] ** 2 * N * 64 * 147)]
+        out = [(self.stem, b["xin"], b["y0"], S + 6, S + 6, dict(cin=4, kw=8, pad=0), b["y0"].shape[1] ** 2 * N * 64 * 147, None)]
         x = b["x0"]
         for blk, e in zip(self.blocks, b["blocks"]):
             c1, c2, c3, ds = blk["c1"], blk["c2"], blk["c3"], blk["ds"]
             hin, ho = e["hin"], e["hout"]
-            seq = [(c1, x, e["y1"], hin), (c2, e["z1"], e["y2"], ho if blk["kind"] == "basic" else hin)]
+            seq = [(c1, x, e["y1"], hin, None),
+                   (c2, e["z1"], e["y2"], ho if blk["kind"] == "basic" else hin, None)]
             if c3 is not None:
-                seq.append((c3, e["z2"], e["y3"], ho))
+                seq.append((c3, e["z2"], e["y3"], ho, (c2, e["y2"], b["rows"][c2.name])))
             if ds is not None:
-                seq.append((ds, x, e["yd"], hin))
-            for s, xi, yo, hh in seq:
-                out.append((s, xi, yo, hh, hh, {}, yo.shape[0] * yo.shape[1] * yo.shape[2] * s.cout * s.cin * s.k * s.k))
+                seq.append((ds, x, e["yd"], hin, None))
+            for s, xi, yo, hh, prev in seq:
+                out.append((s, xi, yo, hh, hh, {}, yo.shape[0] * yo.shape[1] * yo.shape[2] * s.cout * s.cin * s.k * s.k, prev))
             x = e["out"]
         return out
 
@@ -343,10 +375,11 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None):
     stream = torch.cuda.current_stream()
     b = plan._buffers(N, S, encoder.linear.weight.device)
     seen = {}
-    for s, xi, yo, H, W, kw, macs in plan.conv_shapes(N, S):
-        key = (s.cin, s.cout, s.k, s.stride, H)
+    for s, xi, yo, H, W, kw, macs, prev in plan.conv_shapes(N, S):
+        key = (s.cin, s.cout, s.k, s.stride, H, bool(prev is not None and s.fused_in))
         if key not in seen:
-            seen[key] = [event_time_ms(lambda: plan._conv(s, xi, yo, b["stats"], N, H, W, **kw), 5, stream), 0, macs, s.name]
+            seen[key] = [event_time_ms(lambda: plan.replay(s, xi, yo, b["stats"], N, H, W, kw, prev), 5, stream), 0, macs,
+                         s.name + (" [bn+relu on load]" if key[5] else "")]
         seen[key][1] += 1
     total_ms = total_flops = bound_us = total_bytes = 0.0
     launches = 0
@@ -362,14 +395,14 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None):
         floor_us = max(2.0 * macs / (peak_tflops * 1e12), nbytes / 8e12) * 1e6
         bound_us += floor_us * count
         total_bytes += nbytes * count
-        print(f"[conv] {name:22s} Cin={key[0]:5d} Cout={key[1]:5d} k={key[2]} s={key[3]} H={key[4]:4d} x{count}: {ms * 1e3:8.1f} us {tf:7.1f} TFLOP/s "
+        print(f"[conv] {name:30s} Cin={key[0]:5d} Cout={key[1]:5d} k={key[2]} s={key[3]} H={key[4]:4d} x{count}: {ms * 1e3:8.1f} us {tf:7.1f} TFLOP/s "
               f"{nbytes / (ms * 1e-3) / 1e9:7.0f} GB/s  roofline floor {floor_us:6.1f} us", file=sys.stderr)
     print(f"[conv] all {launches} launches: {total_ms * 1e3:.1f} us; per-layer max(MFMA, HBM) floor {bound_us:.1f} us", file=sys.stderr)
     layers.sort()
     achieved = total_flops / (total_ms * 1e-3) / 1e12
     fmt = lambda l: {"layer": l[1], "cin": l[2][0], "cout": l[2][1], "k": l[2][2], "stride": l[2][3], "tflops": round(l[0], 1), "us": round(l[3] * 1e3, 1)}
     return {"kernel": "tile8_kernel<CONV, EPI_BNSTATS>: implicit-GEMM convolution, bf16 16x16x32 MFMA, 128x128|128x64 tile, 8 waves, LDS-DMA ring, "
-                      f"{launches} launches/step (every trunk convolution)",
+                      f"{launches} launches/step (every trunk convolution; the 16 conv3 launches also apply bn2 + ReLU to their A tiles in LDS)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(achieved / peak_tflops, 4),
             "traffic": pmc_traffic, "ms_per_launch": round(total_ms / launches, 5), "launches_per_step": launches,
             "ms_per_step": round(total_ms, 4), "algorithmic_gflop_per_step": round(total_flops / 1e9, 1),

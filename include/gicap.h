@@ -240,6 +240,17 @@ int gic_repack_conv_weight(const float* w, void* out, int dtype, int Cout, int C
  * statistics nn.BatchNorm2d needs in train mode.  Replaces nn.Conv2d of the torchvision trunk (generator.py:12-14,22). */
 int gic_conv2d(const void* in, const void* w, void* out, float* stats, int stats_nrep, int dtype, int N, int H, int W, int Cin,
                int Cout, int KH, int KW, int stride, int pad, void* stream);
+
+/* Convolution whose INPUT is normalised on the fly: out = conv(pad(relu(gamma (in - mean) / sqrt(var + 1e-5) + beta))) with
+ * mean / var from `in_stats` ([in_nrep][2*Cin] sums written by the gic_conv2d that produced `in`, over in_count rows).  Replaces the
+ * bn -> ReLU -> conv links inside the torchvision residual blocks (src/generator.py:12-14) without the separate gic_bn_act pass
+ * and without the normalised tensor: the kernel rewrites each A tile in LDS before its MFMAs (padding taps stay zero).  `stats`
+ * receives this convolution's own column sums as gic_conv2d does.  Returns GIC_STATUS_UNSUPPORTED (and launches nothing) in f32
+ * mode, for Cin > 1024 or Cin % 8 != 0, or for shapes the 8-wave kernel does not take: the caller then runs gic_bn_act +
+ * gic_conv2d. */
+int gic_conv2d_bn_in(const void* in, const float* in_stats, int in_nrep, const float* in_gamma, const float* in_beta, float in_count,
+                     const void* w, void* out, float* stats, int stats_nrep, int dtype, int N, int H, int W, int Cin, int Cout, int KH,
+                     int KW, int stride, int pad, void* stream);
 /* out = [relu]( bn(y) + (res ? bn_res(res) : 0) ) over rows x C.  A BatchNorm takes its mean/var from `stats` (raw sums over
  * `count` rows; train mode) or from run_mean/run_var (eval mode); res_gamma == NULL -> the residual is added as is. */
 int gic_bn_act(const void* y, const float* stats, const float* gamma, const float* beta, const float* run_mean,

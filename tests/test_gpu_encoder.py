@@ -262,3 +262,57 @@ def test_trunk_prefetch_is_equivalent(dev, dtype):
     assert outs["plain"][3] == 3 and outs["prefetch"][3] == 4
     if dtype == "fp32":
         torch.testing.assert_close(outs["plain"][2], outs["prefetch"][2], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", [(8, 28, 128, 512, 1, 1, 0), (4, 56, 64, 256, 1, 1, 0), (16, 14, 256, 1024, 1, 1, 0), (2, 7, 512, 2048, 1, 1, 0),
+                                  (3, 9, 72, 40, 1, 1, 0), (4, 28, 128, 128, 3, 1, 1), (4, 28, 128, 128, 3, 2, 1), (8, 56, 64, 64, 3, 1, 1),
+                                  (16, 14, 256, 256, 3, 1, 1)])
+def test_conv_with_input_batchnorm_equals_bn_act_then_conv(dev, case):
+    """gic_conv2d_bn_in (bn + ReLU applied to the A tiles in LDS, padding taps left at zero) against gic_bn_act followed by
+    gic_conv2d on the same raw tensor and statistics: same bf16 input to the MFMAs, so outputs and column sums agree to rounding."""
+    from gan_image_captioning_amd import engine
+    L = _lib()
+    lib = L.load()
+    N, H, Ci, Co, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    rows = N * H * H
+    Ho = (H + 2 * pad - k) // stride + 1
+    rows_out = N * Ho * Ho
+    y_prev = (torch.randn(rows, Ci, generator=g) * 1.5 + 0.3).to(dev).bfloat16()
+    gamma = (torch.rand(Ci, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(Ci, generator=g) * 0.2).to(dev)
+    w = (torch.randn(Co, k, k, Ci, generator=g) * 0.05).to(dev).bfloat16()          # packed [Cout, KH, KW, Cin]
+    nrep = 4
+    yf = y_prev.float()
+    in_stats = torch.zeros(nrep, 2 * Ci, device=dev)
+    in_stats[1, :Ci] = yf.sum(0)
+    in_stats[2, Ci:] = (yf * yf).sum(0)                 # replicas are summed by the readers
+    s = engine.stream_ptr()
+    if Ci & (Ci - 1) == 0:                              # reference route: bn_act -> conv2d
+        z = torch.empty_like(y_prev)
+        L.check(lib.gic_bn_act(y_prev.data_ptr(), in_stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, None, None, None, None, None,
+                               None, None, nrep, float(rows), 1, z.data_ptr(), 1, rows, Ci, s), "bn_act")
+    else:                                               # bn_act wants a power-of-two C: normalise on the host for the odd case
+        mean = in_stats.sum(0)[:Ci] / rows
+        var = (in_stats.sum(0)[Ci:] / rows - mean * mean).clamp_min(0)
+        sc = gamma * torch.rsqrt(var + 1e-5)
+        z = torch.relu(yf * sc + (beta - mean * sc)).bfloat16()
+    out_ref = torch.empty(rows_out, Co, device=dev, dtype=torch.bfloat16)
+    st_ref = torch.zeros(nrep, 2 * Co, device=dev)
+    L.check(lib.gic_conv2d(z.data_ptr(), w.data_ptr(), out_ref.data_ptr(), st_ref.data_ptr(), nrep, 1, N, H, H, Ci, Co, k, k, stride, pad, s),
+            "conv2d")
+    out = torch.empty_like(out_ref)
+    st = torch.zeros_like(st_ref)
+    args = (y_prev.data_ptr(), in_stats.data_ptr(), nrep, gamma.data_ptr(), beta.data_ptr(), float(rows), w.data_ptr(), out.data_ptr(),
+            st.data_ptr(), nrep)
+    status = lib.gic_conv2d_bn_in(*args, 1, N, H, H, Ci, Co, k, k, stride, pad, s)
+    torch.cuda.synchronize()
+    if rows_out < 128:
+        assert status == L.ERR_UNSUPPORTED            # below one tile of rows the 8-wave kernel declines; the plan falls back
+        return
+    L.check(status, "conv2d_bn_in")
+    err = float((out.float() - out_ref.float()).abs().max() / out_ref.float().abs().max())
+    assert err < 1e-2, err
+    torch.testing.assert_close(st.sum(0), st_ref.sum(0), rtol=2e-3, atol=2e-2 * rows_out ** 0.5)
+    # f32 mode has no fused variant
+    assert lib.gic_conv2d_bn_in(*args, 0, N, H, H, Ci, Co, k, k, stride, pad, s) == L.ERR_UNSUPPORTED
