@@ -374,12 +374,14 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None):
     N, S = args.adv_train_batch_size, args.image_size
     stream = torch.cuda.current_stream()
     b = plan._buffers(N, S, encoder.linear.weight.device)
-    seen = {}
+    seen, plain_ms = {}, {}
     for s, xi, yo, H, W, kw, macs, prev in plan.conv_shapes(N, S):
         key = (s.cin, s.cout, s.k, s.stride, H, bool(prev is not None and s.fused_in))
         if key not in seen:
             seen[key] = [event_time_ms(lambda: plan.replay(s, xi, yo, b["stats"], N, H, W, kw, prev), 5, stream), 0, macs,
                          s.name + (" [bn+relu on load]" if key[5] else "")]
+            # the same layer as a plain convolution (its input normalised by a separate bn_act launch): for the side figure below
+            plain_ms[key] = event_time_ms(lambda: plan.replay(s, xi, yo, b["stats"], N, H, W, kw, None), 5, stream) if key[5] else seen[key][0]
         seen[key][1] += 1
     total_ms = total_flops = bound_us = total_bytes = 0.0
     launches = 0
@@ -400,6 +402,7 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None):
     print(f"[conv] all {launches} launches: {total_ms * 1e3:.1f} us; per-layer max(MFMA, HBM) floor {bound_us:.1f} us", file=sys.stderr)
     layers.sort()
     achieved = total_flops / (total_ms * 1e-3) / 1e12
+    plain_total = sum(plain_ms[k] * v[1] for k, v in seen.items())
     fmt = lambda l: {"layer": l[1], "cin": l[2][0], "cout": l[2][1], "k": l[2][2], "stride": l[2][3], "tflops": round(l[0], 1), "us": round(l[3] * 1e3, 1)}
     return {"kernel": "tile8_kernel<CONV, EPI_BNSTATS>: implicit-GEMM convolution, bf16 16x16x32 MFMA, 128x128|128x64 tile, 8 waves, LDS-DMA ring, "
                       f"{launches} launches/step (every trunk convolution; the 16 conv3 launches also apply bn2 + ReLU to their A tiles in LDS)",
@@ -409,4 +412,7 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None):
             "algorithmic_bytes_per_launch": int(total_bytes / launches),
             "floor_ms_per_step": round(bound_us / 1e3, 4),      # sum over layers of max(flops / MFMA peak, bytes / 8 TB/s)
             "frac_of_floor": round(bound_us / 1e3 / total_ms, 4),
+            # the same 53 layers with every input normalised by its own bn_act launch instead (what the fused launches replace)
+            "plain_conv_variant": {"ms_per_step": round(plain_total, 4), "achieved": round(total_flops / (plain_total * 1e-3) / 1e12, 2),
+                                   "frac": round(total_flops / (plain_total * 1e-3) / 1e12 / peak_tflops, 4)},
             "slowest_layer": fmt(layers[0]), "fastest_layer": fmt(layers[-1])}
