@@ -84,31 +84,8 @@ class FusedAdvStep:
             self._s_gen = torch.cuda.Stream(device=dev)      # the generator's path: D(gen) forward / backward, decoder backward
         return self._s_real, self._s_gen
 
-    # ---- trunk prefetch: the ResNet trunk is frozen (generator.py:21), so the trunk forward of batch k+1 depends on nothing
-    # that step k updates.  It is enqueued on its own stream while step k is in its launch-bound phases (roll-out, D, BPTT).
-    def _prefetch_trunk(self, images, train: bool, after) -> None:
-        if getattr(self, "_s_pre", None) is None:
-            prio = int(os.environ.get("GIC_PREFETCH_PRIORITY", "0"))
-            self._s_pre = torch.cuda.Stream(device=images.device, priority=prio)
-        s = self._s_pre
-        with torch.cuda.stream(s):
-            s.wait_event(after)                 # `images` is ready and the previous trunk output has been consumed
-            self._mark("trunk prefetch start [s_pre]", s)
-            feats = self.gen.encoder.trunk_features(images, train).clone()
-            done = s.record_event()
-            self._mark("trunk prefetch done [s_pre]", s)
-        images.record_stream(s)
-        self._pre = (images, bool(train), feats, done)
-
-    def _trunk_features(self, images, train: bool, main):
-        pre, self._pre = getattr(self, "_pre", None), None
-        if pre is not None:
-            main.wait_event(pre[3])             # also orders a synchronous trunk pass behind an unused prefetch (shared buffers)
-            if pre[0] is images and pre[1] == bool(train):
-                pre[2].record_stream(main)
-                return pre[2]
-        return self.gen.encoder.trunk_features(images, train)
-
+    # ---- trunk look-ahead (Encoder.prefetch_trunk / take_trunk): the ResNet trunk is frozen (generator.py:21), so the trunk forward
+    # of batch k+1 depends on nothing that step k updates; it runs on its own stream under this step's launch-bound phases.
     def __call__(self, images, captions, max_caption_len: int, train: bool = True, noise_u=None, keep_masks=None,
                  opt_step: bool = True, next_images=None, next_train=None) -> dict:
         """One step.  Returns device tensors: losses [g_loss, d_loss], ids, probs, logits (real, fake, gen).
@@ -162,9 +139,9 @@ class FusedAdvStep:
 
         # ---- features (training.py:144-147) and one roll-out (training.py:150)
         if self.cgan:
-            trunk_feats = self._trunk_features(images, train, main)
+            trunk_feats = gen.encoder.take_trunk(images, train, main)
             if next_images is not None:          # the prefetched output is a private copy: the next trunk pass may start now
-                self._prefetch_trunk(next_images, train if next_train is None else next_train, ev_start)
+                gen.encoder.prefetch_trunk(next_images, train if next_train is None else next_train, ev_start, mark=self._mark)
             feats = gen.encoder.forward_fused(images, train, trunk_feats=trunk_feats)
         else:
             feats = engine.embedding_fwd(gparams[0], buf["ones"])

@@ -198,13 +198,46 @@ class Encoder(nn.Module):
         self.bn = _BatchNorm1dParams(args.gen_embed_dim, momentum=0.01)
         self.args = args
 
-    def forward(self, images):
+    def forward(self, images, next_images=None):
+        """generator.py:19-25.  ``next_images`` (optional, the next batch's images): their trunk forward is enqueued on the look-ahead
+        stream now and picked up by the next call that is handed the same tensor."""
         with torch.no_grad():                                        # generator.py:21-22
-            feats = self.resnet(images, _compute_dtype(self.args))
+            main = torch.cuda.current_stream(images.device)
+            start = main.record_event()
+            feats = self.take_trunk(images, self.training, main)
+            if next_images is not None:
+                self.prefetch_trunk(next_images, self.training, start)
         feats = feats.reshape(feats.size(0), -1)
         return _EncoderHeadFn.apply(_compute_dtype(self.args), self.training, self.bn.momentum, self.bn.eps, feats,
                                     self.linear.weight, self.linear.bias, self.bn.weight, self.bn.bias,
                                     self.bn.running_mean, self.bn.running_var)
+
+    # ---- trunk look-ahead: the trunk is frozen (generator.py:21), so the pass for the NEXT batch depends on nothing the current
+    # step updates; it runs on its own stream under the step's launch-bound phases and hands over a private copy of its output.
+    def prefetch_trunk(self, images, training: bool, after, mark=None) -> None:
+        if getattr(self, "_s_pre", None) is None:
+            self._s_pre = torch.cuda.Stream(device=images.device)
+        s = self._s_pre
+        with torch.cuda.stream(s):
+            s.wait_event(after)                 # `images` is ready
+            if mark is not None:
+                mark("trunk prefetch start [s_pre]", s)
+            feats = self.trunk_features(images, training).clone()
+            done = s.record_event()
+            if mark is not None:
+                mark("trunk prefetch done [s_pre]", s)
+        images.record_stream(s)
+        self._pre = (images, bool(training), feats, done)
+
+    def take_trunk(self, images, training: bool, stream):
+        """Trunk features of ``images`` on ``stream``: the prefetched copy if this very tensor was announced, else a pass now."""
+        pre, self._pre = getattr(self, "_pre", None), None
+        if pre is not None:
+            stream.wait_event(pre[3])           # also orders a synchronous pass behind an unused look-ahead (shared buffers)
+            if pre[0] is images and pre[1] == bool(training):
+                pre[2].record_stream(stream)
+                return pre[2]
+        return self.trunk_features(images, training)
 
     # ---- direct (no autograd) forms used by the fused step driver
     def trunk_features(self, images, training: bool):

@@ -120,9 +120,9 @@ class GANInstructor:
         self.adv_epoch = -1
 
     # ------------------------------------------------------------------ shared pieces
-    def _features(self, images, batch):
+    def _features(self, images, batch, next_images=None):
         if self.cgan:
-            return self.gen.encoder(images)                                # training.py:66,145
+            return self.gen.encoder(images, next_images=next_images)       # training.py:66,145
         ones = torch.ones(batch, dtype=torch.long, device=self.args.device)
         return self.gen.decoder.embed(ones)                                # training.py:68,147
 
@@ -139,8 +139,8 @@ class GANInstructor:
         opt.step()
 
     # ------------------------------------------------------------------ MLE pre-training (training.py:48-126)
-    def pretrain_step(self, images, captions, max_caption_len, train=True):
-        feats = self._features(images, captions.shape[0])
+    def pretrain_step(self, images, captions, max_caption_len, train=True, next_images=None):
+        feats = self._features(images, captions.shape[0], next_images)
         gen_captions, _ids = self.gen.decoder.sample(feats, pretrain=True, max_caption_len=max_caption_len)
         flat = gen_captions.reshape(-1, gen_captions.size(-1))
         loss = _XentFn.apply(flat, captions.reshape(-1))                   # nn.CrossEntropyLoss(), training.py:81-83
@@ -154,9 +154,9 @@ class GANInstructor:
         total = len(self.train_dataset) if what == "train" else len(self.dev_dataset)
         with (torch.enable_grad() if what == "train" else torch.no_grad()), \
                 tqdm(total=total, disable=self.dist.rank != 0) as progress:
-            for images, captions, lengths, max_caption_len in loader:
-                images, captions = images.to(self.args.device), captions.to(self.args.device)
-                loss = self.pretrain_step(images, captions, max_caption_len, train=(what == "train"))
+            for (images, captions, lengths, max_caption_len), nxt in _lookahead(loader, self.args.device):
+                loss = self.pretrain_step(images, captions, max_caption_len, train=(what == "train"),
+                                          next_images=nxt[0] if nxt is not None and nxt[0].shape == images.shape else None)
                 val = loss.item()
                 gen_loss.append(val)
                 self.writer.add_scalar("GenPreTraining_train_loss" if what == "train" else "GenPreTraining_val_loss",
