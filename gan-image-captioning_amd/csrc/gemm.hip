@@ -534,7 +534,7 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
   constexpr int NL = CA + CB;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int OSZ = sizeof(TO), OVE = 16 / OSZ, SC = BN * OSZ + 16;
-  constexpr int EPI_BYTES = BM * SC + 8 * (BN / 2) * 2 * 4;
+  constexpr int EPI_BYTES = EPI == EPI_HIGHWAY ? BM * (BN + 4) * 4 : BM * SC + 8 * (BN / 2) * 2 * 4;   // highway stages h in f32
   constexpr int RING_BYTES = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
   constexpr int ABN_MAXK = 1024;                              // A-side BatchNorm: [scale, shift] per input channel behind the ring
   constexpr int SMEM_BYTES = RING_BYTES + (ABN ? ABN_MAXK * 8 : 0);
@@ -797,8 +797,72 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
 
   TO* __restrict__ C = (TO*)d.C;
   if constexpr (EPI == EPI_HIGHWAY) {
-    // h = acc + bias (saved); y = sig(h) relu(h) + (1 - sig(h)) x; C = y * keep * keep_scale.  Per-element stores of the MFMA
-    // layout (as in gemm_kernel): X / Hpre / mask traffic dominates this epilogue, not the store shape.
+    // h = acc + bias (saved); y = sig(h) relu(h) + (1 - sig(h)) x; C = y * keep * keep_scale.
+    // Row-padded operands (every leading dimension covers whole 8-column groups, as the discriminator's Fp-padded buffers do):
+    // h goes through LDS and each thread owns a 4-row x 8-column patch = one Philox draw per column (4 rows each), 16-byte
+    // accesses to X / Hpre / C and 8-byte ones to the keep mask.  Pad columns of C are written as zero.
+    const int n8 = (N + 7) & ~7;
+    const bool wide = sizeof(TO) == 2 && d.ldc >= n8 && d.ldx >= n8 && d.ldh >= n8 && (!d.mask_out || d.ldmask_out >= n8) &&
+                      d.ldc % 8 == 0 && d.ldx % 8 == 0 && d.ldh % 4 == 0 && (!d.mask_out || d.ldmask_out % 8 == 0) &&
+                      ((((uintptr_t)d.C) | ((uintptr_t)d.X) | ((uintptr_t)d.Hpre)) & 15) == 0 && (((uintptr_t)d.mask_out) & 7) == 0;
+    if (wide) {
+      constexpr int SH = BN + 4;
+      float* sH = (float*)smem;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nl = wc * (BN / 2) + j * 16 + lr;
+        const float bias = (d.bias && bn0 + nl < N) ? d.bias[bn0 + nl] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sH[(wr * 32 + i * 16 + lg * 4 + r) * SH + nl] = d.alpha * acc[i][j][r] + bias;
+      }
+      __syncthreads();
+      constexpr int CG = BN / 8;
+      const int pc = tid % CG, pr = tid / CG;
+      const int n0 = bn0 + pc * 8, m0 = bm0 + pr * 4;
+      if (pr < BM / 4 && n0 < N && m0 < M) {
+        float keep[4][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          keep[0][e] = keep[1][e] = keep[2][e] = keep[3][e] = 1.f;
+          if (!d.mask && d.use_philox && n0 + e < N) {
+            uint32_t r0, r1, r2, r3;
+            Philox::gen4(d.seed, d.stream, (uint64_t)(m0 >> 2) * (uint64_t)N + (uint64_t)(n0 + e), r0, r1, r2, r3);
+            keep[0][e] = Philox::u01(r0) >= d.drop_p ? 1.f : 0.f;
+            keep[1][e] = Philox::u01(r1) >= d.drop_p ? 1.f : 0.f;
+            keep[2][e] = Philox::u01(r2) >= d.drop_p ? 1.f : 0.f;
+            keep[3][e] = Philox::u01(r3) >= d.drop_p ? 1.f : 0.f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + r;
+          if (m >= M) break;
+          const float4 h0 = *(const float4*)(sH + (pr * 4 + r) * SH + pc * 8), h1 = *(const float4*)(sH + (pr * 4 + r) * SH + pc * 8 + 4);
+          const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+          const bf16x8 xv = *(const bf16x8*)((const bf16_t*)d.X + (long)m * d.ldx + n0);
+          bf16x8 yv;
+          unsigned long long kb = 0ull;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const bool live = n0 + e < N;
+            const float sg = 1.f / (1.f + expf(-h[e]));
+            const float y = sg * fmaxf(h[e], 0.f) + (1.f - sg) * (float)xv[e];
+            float k = keep[r][e];
+            if (d.mask && live) k = (float)d.mask[(long)m * d.ldmask + n0 + e];
+            kb |= (unsigned long long)(live ? (unsigned)k : 0u) << (8 * e);
+            yv[e] = (bf16_t)(live ? y * k * d.keep_scale : 0.f);
+          }
+          *(float4*)(d.Hpre + (long)m * d.ldh + n0) = h0;
+          *(float4*)(d.Hpre + (long)m * d.ldh + n0 + 4) = h1;
+          if (d.mask_out) *(unsigned long long*)(d.mask_out + (long)m * d.ldmask_out + n0) = kb;
+          *(bf16x8*)((bf16_t*)C + (long)m * d.ldc + n0) = yv;
+        }
+      }
+      STAMP(5);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll

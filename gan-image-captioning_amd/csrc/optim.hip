@@ -20,8 +20,19 @@ __global__ __launch_bounds__(1024) void gan_losses_kernel(int type, const float*
   __shared__ float red[16];
   const float inv = 1.f / (float)n;
   float sd = 0.f, sg = 0.f;
-  for (long i = threadIdx.x; i < n; i += blockDim.x) {
-    const float r = dr[i], f = df[i], g = go[i];
+  // 4 strided elements per pass with their 12 loads issued together (n = B*R = 4096: one pass of the 1024 threads)
+  for (long i0 = threadIdx.x; i0 < n; i0 += 4L * blockDim.x) {
+   float rr[4], ff[4], gg[4];
+#pragma unroll
+   for (int q = 0; q < 4; ++q) {
+     const long i = i0 + (long)q * blockDim.x;
+     rr[q] = i < n ? dr[i] : 0.f; ff[q] = i < n ? df[i] : 0.f; gg[q] = i < n ? go[i] : 0.f;
+   }
+#pragma unroll
+   for (int q = 0; q < 4; ++q) {
+    const long i = i0 + (long)q * blockDim.x;
+    if (i >= n) break;
+    const float r = rr[q], f = ff[q], g = gg[q];
     float ld = 0.f, lg = 0.f, gdr = 0.f, gdf = 0.f, ggo = 0.f, ggr = 0.f, ggf = 0.f;
     switch (type) {
       case GIC_LOSS_STANDARD:
@@ -55,6 +66,7 @@ __global__ __launch_bounds__(1024) void gan_losses_kernel(int type, const float*
     if (dg_out) dg_out[i] = ggo * inv;
     if (dg_real) dg_real[i] = ggr * inv;
     if (dg_fake) dg_fake[i] = ggf * inv;
+   }
   }
   sd = block_sum(sd, red);
   sg = block_sum(sg, red);

@@ -504,6 +504,18 @@ def test_bf16_discriminator_at_bench_batch(E, dev):
         assert e < (8e-2 if n.startswith(("convs", "embeddings", "d_inp")) else 3e-2), (n, errs)
     for n, g1, g2 in zip(dnames, dgr, dgr2):
         assert rel_l2(g2, 2 * g1) < 2e-2, n
+    # device-drawn dropout on the wide kernel: reproducible per seed, rate 0.2, and the same (seed, row, column) -> draw map as the
+    # element-wise re-draw kernel that serves D(gen) in the step
+    l1, st1 = deng.fwd(dparams, sd, None, True, None, seed=123)
+    l2, st2 = deng.fwd(dparams, sd, None, True, None, seed=123)
+    st3 = deng.shared_state(st1, B, Lc, dev)
+    deng.fwd_redrop(dparams, st1, st3, True, None, seed=123)
+    torch.cuda.synchronize()
+    k1 = st1["keep"][:, :900]
+    assert torch.equal(k1, st2["keep"][:, :900]) and torch.equal(k1, st3["keep"][:, :900])
+    assert abs(float(k1.float().mean()) - 0.8) < 0.01
+    assert float(st1["ydrop"][:, 900:].abs().max()) == 0.0            # pad columns of the dropped output stay zero
+    assert torch.equal(st1["ydrop"], st3["ydrop"])
 
 
 def test_no_cpu_fallback(E):
