@@ -95,6 +95,9 @@ _SIGNATURES = {
     "gic_decoder_prepare": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), c_void_p]),
     "gic_decoder_sample_fwd": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), _P(DecoderState), c_void_p,
                                          c_void_p, C.c_uint64, C.c_float, C.c_int, c_void_p, c_void_p, c_void_p]),
+    "gic_decoder_forward_tf": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), _P(DecoderState), c_void_p, c_void_p,
+                                         c_void_p, C.c_int, c_void_p, C.c_uint64, C.c_float, C.c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]),
     "gic_decoder_sample_bwd": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), _P(DecoderState),
                                          _P(DecoderBwdWs), c_void_p, c_void_p, c_void_p, C.c_float, C.c_int,
                                          _P(DecoderGrads), C.c_int, c_void_p]),

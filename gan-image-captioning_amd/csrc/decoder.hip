@@ -426,7 +426,126 @@ __global__ void embed_scatter_time_kernel(const float* __restrict__ dxh0, long l
 
 using namespace gic;
 
+// ---- teacher-forced decode (Decoder.forward, generator.py:39-53): inputs known up front, packed-sequence semantics
+// x rows of slots 1..T-1 of XH_0: embed(caps[b, t-1])
+template <typename TA>
+__global__ void embed_rows_tf_kernel(const float* __restrict__ embed, const int64_t* __restrict__ caps, TA* __restrict__ xh0, long ld,
+                                     int B, int Tm1, int E, int V) {
+  const long total = (long)Tm1 * B * E;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i % E);
+    const long r = i / E;
+    const int b = (int)(r % B), t = (int)(r / B) + 1;
+    long id = caps[(long)b * Tm1 + (t - 1)];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    xh0[((long)t * B + b) * ld + e] = from_f32<TA>(embed[id * E + e]);
+  }
+}
+
+// LSTM pointwise with pack_padded_sequence semantics: a row past its length keeps (h, c) and outputs zero
+template <typename TA>
+__global__ void lstm_pointwise_tf_kernel(const float* __restrict__ gpre, const float* __restrict__ c_prev, const TA* __restrict__ h_prev,
+                                         long ld_prev, float* __restrict__ c_new, TA* __restrict__ h_next, long ld_next,
+                                         TA* __restrict__ h_up, long ld_up, TA* __restrict__ h_out, long ld_out,
+                                         const int32_t* __restrict__ lengths, int t, int B, int H) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * H) return;
+  const int b = idx / H, j = idx % H;
+  if (t >= lengths[b]) {
+    c_new[idx] = c_prev[idx];
+    const TA hp = h_prev[(long)b * ld_prev + j];
+    h_next[(long)b * ld_next + j] = hp;
+    if (h_up) h_up[(long)b * ld_up + j] = hp;
+    if (h_out) h_out[(long)b * ld_out + j] = from_f32<TA>(0.f);
+    return;
+  }
+  const float* g = gpre + (long)b * 4 * H;
+  const float i_ = sigmoidf_(g[j]);
+  const float f_ = sigmoidf_(g[H + j]);
+  const float g_ = tanhf(g[2 * H + j]);
+  const float o_ = sigmoidf_(g[3 * H + j]);
+  const float c = f_ * c_prev[idx] + i_ * g_;
+  const float h = o_ * tanhf(c);
+  c_new[idx] = c;
+  h_next[(long)b * ld_next + j] = from_f32<TA>(h);
+  if (h_up) h_up[(long)b * ld_up + j] = from_f32<TA>(h);
+  if (h_out) h_out[(long)b * ld_out + j] = from_f32<TA>(h);
+}
+
+template <typename TA>
+int forward_tf_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_shadow* S, const gic_decoder_state* st,
+                 const float* features, const int64_t* caps, const int32_t* lengths, int Tmax, const float* noise_u, uint64_t seed,
+                 float temperature, int pretrain, float* logits_ws, int64_t* ids_ws, void* out, float* h_n, float* c_n,
+                 hipStream_t stream) {
+  const int B = c.B, T = c.L, V = c.V, E = c.E, H = c.H, NL = c.NL;
+  const int pw_grid = cdiv((long)B * H, 256);
+  for (int l = 0; l < NL; ++l) {
+    GIC_PROPAGATE(fill_zero(st->xh[l], (size_t)B * c.ldx(l) * c.asz(), stream));
+    GIC_PROPAGATE(fill_zero(st->c[l], (size_t)B * H * sizeof(float), stream));
+  }
+  GIC_PROPAGATE(cast2d(features, DT_F32, E, st->xh[0], c.dt, c.ldx(0), B, E, stream));
+  if (T > 1) {
+    const long total = (long)(T - 1) * B * E;
+    hipLaunchKernelGGL((embed_rows_tf_kernel<TA>), dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256), 0,
+                       stream, P->embed, caps, (TA*)st->xh[0], c.ldx(0), B, T - 1, E, V);
+    GIC_CHECK_LAUNCH("embed_rows_tf");
+  }
+  for (int t = 0; t < Tmax; ++t) {
+    for (int l = 0; l < NL; ++l) {
+      const long ld = c.ldx(l);
+      TA* xh_t = (TA*)st->xh[l] + (long)t * B * ld;
+      TA* xh_n = (TA*)st->xh[l] + (long)(t + 1) * B * ld;
+      GemmDesc g;
+      g.A = xh_t; g.lda = ld; g.B = S->wcat[l]; g.ldb = ld; g.C = st->gpre; g.ldc = 4 * H;
+      g.M = B; g.N = 4 * H; g.K = (int)ld; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.bias = S->bsum[l];
+      GIC_PROPAGATE(gemm(g, stream));
+      TA* h_up = (l + 1 < NL) ? (TA*)st->xh[l + 1] + (long)t * B * c.ldx(l + 1) : nullptr;
+      TA* h_out = (l + 1 == NL) ? (TA*)st->hout + (long)t * H : nullptr;            // hout viewed as [B, Tmax, H]
+      hipLaunchKernelGGL((lstm_pointwise_tf_kernel<TA>), dim3(pw_grid), dim3(256), 0, stream, (const float*)st->gpre,
+                         (const float*)(st->c[l] + (long)t * B * H), (const TA*)(xh_t + c.din(l)), ld,
+                         st->c[l] + (long)(t + 1) * B * H, xh_n + c.din(l), ld, h_up, h_up ? c.ldx(l + 1) : 0, h_out, (long)Tmax * H,
+                         lengths, t, B, H);
+      GIC_CHECK_LAUNCH("lstm_pointwise_tf");
+    }
+  }
+  // one projection over all B*Tmax rows, then (adversarial mode) Gumbel + softmax per row; the draw u is [B, Tmax, V]
+  const long rows = (long)B * Tmax;
+  {
+    GemmDesc g;
+    g.A = st->hout; g.lda = H; g.B = S->wout; g.ldb = H; g.C = logits_ws; g.ldc = V;
+    g.M = (int)rows; g.N = V; g.K = H; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.bias = P->b_out;
+    GIC_PROPAGATE(gemm(g, stream));
+  }
+  hipLaunchKernelGGL((gumbel_softmax_argmax_kernel<TA>), dim3((unsigned)rows), dim3(256), 0, stream, logits_ws, noise_u, seed, (uint64_t)0x7466,
+                     temperature, pretrain, (TA*)out, (long)V, ids_ws, (long)1, P->embed, (TA*)nullptr, (long)0, V, E);
+  GIC_CHECK_LAUNCH("gumbel_softmax (teacher forced)");
+  for (int l = 0; l < NL; ++l) {
+    GIC_PROPAGATE(cast2d((const TA*)st->xh[l] + (long)Tmax * B * c.ldx(l) + c.din(l), c.dt, c.ldx(l), h_n + (long)l * B * H, DT_F32, H, B, H, stream));
+    GIC_PROPAGATE(cast2d(st->c[l] + (long)Tmax * B * H, DT_F32, H, c_n + (long)l * B * H, DT_F32, H, B, H, stream));
+  }
+  return GIC_OK;
+}
+
 extern "C" {
+
+int gic_decoder_forward_tf(const gic_decoder_dims* dims, const gic_decoder_params* P, const gic_decoder_shadow* S,
+                           const gic_decoder_state* st, const float* features, const int64_t* caps, const int32_t* lengths, int Tmax,
+                           const float* noise_u, uint64_t seed, float temperature, int pretrain, float* logits_ws, int64_t* ids_ws,
+                           void* out, float* h_n, float* c_n, void* stream) {
+  Ctx c;
+  GIC_PROPAGATE(check_dims(dims, c));
+  GIC_CHECK_ARG(P && S && st && features && lengths && logits_ws && ids_ws && out && h_n && c_n, "decoder_forward_tf: null argument");
+  GIC_CHECK_ARG(c.L == 1 || caps, "decoder_forward_tf: caps is null");
+  GIC_CHECK_ARG(Tmax >= 1 && Tmax <= c.L, "decoder_forward_tf: Tmax must be in 1..L (= caption length + 1)");
+  GIC_CHECK_ARG(P->embed && P->b_out && S->wout && st->hout && st->gpre, "decoder_forward_tf: null buffer");
+  for (int l = 0; l < c.NL; ++l)
+    GIC_CHECK_ARG(st->xh[l] && st->c[l] && S->wcat[l] && S->bsum[l], "decoder_forward_tf: null layer %d buffer", l);
+  if (c.dt == DT_F32)
+    return forward_tf_t<float>(c, P, S, st, features, caps, lengths, Tmax, noise_u, seed, temperature, pretrain, logits_ws, ids_ws, out,
+                               h_n, c_n, (hipStream_t)stream);
+  return forward_tf_t<bf16_t>(c, P, S, st, features, caps, lengths, Tmax, noise_u, seed, temperature, pretrain, logits_ws, ids_ws, out,
+                              h_n, c_n, (hipStream_t)stream);
+}
 
 int gic_decoder_prepare(const gic_decoder_dims* dims, const gic_decoder_params* P, const gic_decoder_shadow* S, void* stream_) {
   Ctx c;

@@ -265,6 +265,39 @@ class DecoderEngine:
             stream_ptr()), "gic_decoder_sample_fwd")
         return out, ids, st
 
+    def forward_tf(self, params, features: torch.Tensor, caps: torch.Tensor, lengths, temperature: float, pretrain: bool = False,
+                   noise_u: Optional[torch.Tensor] = None, seed: int = 0):
+        """gic_decoder_forward_tf: Decoder.forward (teacher forcing, generator.py:39-53), forward only.
+        Returns (pred act [B, max(lengths), V], (h_n, c_n) f32 [NL, B, H])."""
+        self.check_params(params)
+        require_gpu(features, caps, noise_u)
+        B, Lc = caps.shape
+        T = Lc + 1
+        lens = [int(v) for v in (lengths.tolist() if torch.is_tensor(lengths) else lengths)]
+        if len(lens) != B or min(lens) < 1 or max(lens) > T:
+            raise ValueError(f"lengths must hold {B} values in 1..{T}")
+        Tmax = max(lens)
+        dev = features.device
+        if features.shape != (B, self.E) or caps.dtype != torch.int64:
+            raise ValueError("features must be [B, E] and caps int64 [B, L]")
+        if noise_u is not None and tuple(noise_u.shape) != (B, Tmax, self.V):
+            raise ValueError(f"noise_u must be [B, max(lengths)={Tmax}, V]")
+        self.prepare(params)
+        st = self.alloc_state(B, T, dev)
+        out = torch.empty(B, Tmax, self.V, device=dev, dtype=self.act)
+        h_n = torch.empty(self.NL, B, self.H, device=dev, dtype=torch.float32)
+        c_n = torch.empty_like(h_n)
+        logits_ws = torch.empty(B * Tmax, self.V, device=dev, dtype=torch.float32)
+        ids_ws = torch.empty(B * Tmax, device=dev, dtype=torch.int64)
+        len_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
+        d = self.dims(B, T)
+        L.check(L.load().gic_decoder_forward_tf(
+            C.byref(d), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
+            ptr(features.contiguous().float()), ptr(caps.contiguous()), ptr(len_dev), Tmax,
+            ptr(noise_u.contiguous().float()) if noise_u is not None else None, int(seed) & (2 ** 64 - 1), float(temperature),
+            int(bool(pretrain)), ptr(logits_ws), ptr(ids_ws), ptr(out), ptr(h_n), ptr(c_n), stream_ptr()), "gic_decoder_forward_tf")
+        return out, (h_n, c_n)
+
     def sample_bwd(self, params, st, out: torch.Tensor, ids: torch.Tensor, d_out: torch.Tensor, temperature: float,
                    pretrain: bool = False, ws=None, grads=None, phases: int = 3) -> List[torch.Tensor]:
         """phases: 1 = output layer only (w_out / b_out gradients complete), 2 = recurrent part, 3 = both (gicap.h)."""

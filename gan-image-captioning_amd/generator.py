@@ -149,10 +149,17 @@ class Decoder(nn.Module):
         return _SampleFn.apply(self.engine(), float(self.temperature), bool(pretrain), int(max_caption_len), noise_u, seed,
                                features, *self.param_list())
 
-    def forward(self, features, caps, lengths, pretrain=False):
-        """Teacher-forced decode (generator.py:39-53).  Dead on the training path of the reference (never
-        called by training.py); kept for API completeness and not accelerated."""
-        raise NotImplementedError("Decoder.forward (teacher forcing) is not on the hot path; use sample()")
+    def forward(self, features, caps, lengths, pretrain=False, noise_u=None):
+        """Teacher-forced decode (generator.py:39-53): inputs [features ; embed(caps)] packed with ``lengths``; returns
+        (pred [B, max(lengths), V], (h_n, c_n)) with pred = logits (pretrain) or softmax((logits + gumbel) * temperature).
+        Dead on the reference's training path (training.py never calls it), kept for the module surface: forward only, the
+        results carry no autograd graph (use ``sample`` for anything that is trained through).  ``noise_u`` [B, max(lengths), V]
+        replaces the device draw (parity runs)."""
+        with torch.no_grad():
+            seed = 0 if noise_u is not None else SEEDS.next()
+            pred, hidden = self.engine().forward_tf([p.detach() for p in self.param_list()], features, caps, lengths,
+                                                    float(self.temperature), bool(pretrain), noise_u, seed)
+        return pred, hidden
 
     def add_gumbel(self, o_t, eps=1e-10, gpu=0):
         """o_t + Gumbel(0,1) noise (generator.py:84-96); on the hot path this is fused into sample()."""

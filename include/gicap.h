@@ -129,6 +129,18 @@ int gic_decoder_sample_fwd(const gic_decoder_dims* dims, const gic_decoder_param
                            const float* features, const float* noise_u, uint64_t seed, float temperature,
                            int pretrain, void* out, int64_t* ids, void* stream);
 
+/* Decoder.forward, the teacher-forced decode (src/generator.py:39-53; forward only: the reference's training never calls it).
+ * dims->L = T = caption length + 1 time steps: step 0 is fed `features`, step t > 0 embed(caps[b, t-1]) (caps int64 [B, T-1]).
+ * lengths int32 [B] (each 1..T) with pack_padded_sequence semantics: a row past its length keeps its state and contributes a
+ * zero LSTM output.  Tmax = max(lengths) (the host knows it).  out: act [B, Tmax, V] = logits (pretrain != 0) or
+ * softmax((logits + gumbel(u)) * temperature) with u = noise_u f32 [B, Tmax, V] (ONE draw over the whole tensor,
+ * generator.py:50,86-90) or Philox(seed) when NULL.  h_n / c_n: f32 [NL, B, H], each row's state at ITS last step.
+ * state: as for gic_decoder_sample_fwd with L = T; logits_ws f32 [B*Tmax, V] and ids_ws int64 [B*Tmax]: scratch. */
+int gic_decoder_forward_tf(const gic_decoder_dims* dims, const gic_decoder_params* params, const gic_decoder_shadow* shadow,
+                           const gic_decoder_state* state, const float* features, const int64_t* caps, const int32_t* lengths,
+                           int Tmax, const float* noise_u, uint64_t seed, float temperature, int pretrain, float* logits_ws,
+                           int64_t* ids_ws, void* out, float* h_n, float* c_n, void* stream);
+
 /* d_out: act [B,L,V] gradient w.r.t. `out`; probs = the forward's `out`.
  * phases (bit mask; GIC_DECODER_BWD_ALL = both, in this order):
  *   GIC_DECODER_BWD_OUTPUT     softmax/Gumbel backward, d_hout, and the COMPLETE gradients of the vocabulary projection

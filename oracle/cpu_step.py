@@ -94,6 +94,45 @@ def decoder_sample(gp: Params, features: Tensor, max_caption_len: int,
     return torch.stack(outs, 1), torch.stack(ids, 1)
 
 
+def decoder_forward_tf(gp: Params, features: Tensor, caps: Tensor, lengths: Sequence[int], temperature: float,
+                       pretrain: bool = False, u: Optional[Tensor] = None, prefix: str = "decoder."
+                       ) -> Tuple[Tensor, Tuple[Tensor, Tensor]]:
+    """Decoder.forward, the teacher-forced decode (src/generator.py:39-53).
+
+    Inputs are [features ; embed(caps)] (L+1 steps, :41-42) packed with ``lengths`` (:43): a sequence takes part in step t
+    only while t < its length; afterwards its state is frozen (the returned hidden is the state at ITS last step) and its
+    padded outputs are zero (pad_packed_sequence, :45), so the projection sees zeros there (pred = bias, or its softmax).
+    ``u`` [B, max(lengths), V]: the single uniform_(0,1) draw of add_gumbel over the whole logits tensor (:50, :86-90).
+    Returns (pred [B, max(lengths), V], (h_n, c_n) each [num_layers, B, H])."""
+    nl = num_lstm_layers(gp, prefix)
+    bsz = features.shape[0]
+    hid = gp[f"{prefix}lstm.weight_hh_l0"].shape[1]
+    emb = gp[f"{prefix}embed.weight"][caps]                      # [B, L, E]
+    xs = torch.cat((features.unsqueeze(1), emb), 1)              # [B, L+1, E]
+    lens = torch.as_tensor(list(lengths), dtype=torch.long)
+    tmax = int(lens.max())
+    h = [features.new_zeros(bsz, hid) for _ in range(nl)]
+    c = [features.new_zeros(bsz, hid) for _ in range(nl)]
+    outs = []
+    for t in range(tmax):
+        live = (lens > t).unsqueeze(1)
+        inp = xs[:, t]
+        for l in range(nl):
+            hn, cn = lstm_cell(inp, h[l], c[l], gp[f"{prefix}lstm.weight_ih_l{l}"], gp[f"{prefix}lstm.weight_hh_l{l}"],
+                               gp[f"{prefix}lstm.bias_ih_l{l}"], gp[f"{prefix}lstm.bias_hh_l{l}"])
+            h[l] = torch.where(live, hn, h[l])
+            c[l] = torch.where(live, cn, c[l])
+            inp = h[l]
+        outs.append(torch.where(live, inp, torch.zeros_like(inp)))
+    output = torch.stack(outs, 1)                                # [B, tmax, H]
+    o = output @ gp[f"{prefix}linear.weight"].t() + gp[f"{prefix}linear.bias"]
+    if pretrain:
+        pred = o
+    else:
+        pred = torch.softmax((o + gumbel_from_uniform(u)) * temperature, dim=-1)
+    return pred, (torch.stack(h, 0), torch.stack(c, 0))
+
+
 def start_features(gp: Params, bsz: int, prefix: str = "decoder.") -> Tensor:
     """cgan=0 start feature = embed(<S>=1) broadcast (src/training.py:147)."""
     idx = torch.ones(bsz, dtype=torch.long)

@@ -244,6 +244,39 @@ def run_pretrain_case(case: dict) -> dict:
     return out
 
 
+def run_forward_case(case: dict) -> dict:
+    """Decoder.forward, the teacher-forced decode (generator.py:39-53), in both modes; dead on the training path but part of the
+    module surface."""
+    torch.manual_seed(1008)
+    B, L, V, E, H, NL = (case[k] for k in ("B", "L", "V", "E", "H", "NL"))
+    pg = torch.Generator().manual_seed(case["param_seed"])
+    gp = O.make_gen_params(V, E, H, NL, pg)
+    caps = O.make_captions(B, L, V, pg)
+    feats = torch.randn(B, E, generator=pg) * 0.3
+    lengths = case["lengths"]
+    rg, _, _ = ref_stub.load()
+    args = ref_stub.make_args(V, E, H, NL, temperature=case["T"])
+    dec = rg.Decoder(args)
+    dec.load_state_dict({k[len("decoder."):]: v.clone() for k, v in gp.items()})
+    out = {"caps": _np(caps), "feats": _np(feats), "lengths": np.array(lengths, dtype=np.int32)}
+    for k, v in gp.items():
+        out[f"gp0/{k}"] = _np(v)
+    with torch.no_grad():
+        logits, (h_n, c_n) = dec(feats, caps, torch.tensor(lengths), pretrain=True)
+        state = torch.get_rng_state()
+        probs, (h_n2, c_n2) = dec(feats, caps, torch.tensor(lengths), pretrain=False)
+        torch.set_rng_state(state)
+        u = torch.zeros(probs.size()).uniform_(0, 1)               # the draw add_gumbel made (generator.py:86-90)
+    assert torch.equal(h_n, h_n2) and torch.equal(c_n, c_n2)
+    mine_l, (mh, mc) = O.decoder_forward_tf(gp, feats, caps, lengths, case["T"], pretrain=True)
+    mine_p, _ = O.decoder_forward_tf(gp, feats, caps, lengths, case["T"], pretrain=False, u=u)
+    assert torch.allclose(mine_l, logits, rtol=1e-5, atol=1e-6) and torch.allclose(mine_p, probs, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(mh, h_n, rtol=1e-5, atol=1e-6) and torch.allclose(mc, c_n, rtol=1e-5, atol=1e-6)
+    out.update({"logits": _np(logits), "probs": _np(probs), "u": _np(u), "h_n": _np(h_n), "c_n": _np(c_n)})
+    out["meta"] = np.array(json.dumps(case))
+    return out
+
+
 def run_scalar_cases() -> dict:
     """get_losses for every functional loss type + the temperature schedules."""
     _, _, ru = ref_stub.load()
@@ -279,6 +312,7 @@ CASES = [
     dict(BASE, name="tiny_cgan_head", B=6, L=5, V=50, E=8, H=16, NL=1, nf=[20, 30, 10], steps=2, full=True, trunk_feat_dim=24),
     dict(BASE, name="cfg1", B=8, L=10, V=64, E=32, H=512, NL=1, nf=[300, 300, 300], steps=2, full=False),
 ]
+FORWARD_TF = dict(name="forward_tf_tiny", B=4, L=6, V=50, E=8, H=16, NL=2, T=1.3, lengths=[7, 5, 3, 6], param_seed=2025)
 PRETRAIN = dict(name="pretrain_tiny", B=4, L=6, V=50, E=8, H=16, NL=2, steps=2, clip=5.0, pretrain_lr=1e-2, param_seed=2024)
 
 
@@ -292,6 +326,8 @@ def main() -> int:
     res = run_pretrain_case(PRETRAIN)
     np.savez_compressed(os.path.join(GOLDEN_DIR, "pretrain_tiny.npz"), **res)
     print("pretrain_tiny: loss", res["s0/loss"])
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "forward_tf_tiny.npz"), **run_forward_case(FORWARD_TF))
+    print("forward_tf_tiny written")
     np.savez_compressed(os.path.join(GOLDEN_DIR, "scalars.npz"), **run_scalar_cases())
     return 0
 

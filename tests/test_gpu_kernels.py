@@ -150,6 +150,45 @@ def test_decoder_pretrain_mode_f32(E, dev):
         close(gt, want[n], rtol=2e-3, atol_scale=1e-4, what=n)
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+def test_decoder_teacher_forced_forward_matches_reference(E, dev, dt):
+    """Decoder.forward (generator.py:39-53) against the reference's own run (forward_tf_tiny.npz): packed variable lengths,
+    frozen states, zero outputs past each length, one Gumbel draw over the whole tensor."""
+    g = Golden("forward_tf_tiny")
+    m = g.meta
+    gp = g.group("gp0/")
+    eng = _decoder(E, gp, dt)
+    params = dec_params(gp, dev)
+    lengths = [int(v) for v in g.t("lengths")]
+    feats, caps = g.t("feats").to(dev), g.t("caps").to(dev)
+    logits, (h_n, c_n) = eng.forward_tf(params, feats, caps, lengths, m["T"], pretrain=True)
+    probs, (h2, c2) = eng.forward_tf(params, feats, caps, lengths, m["T"], pretrain=False, noise_u=g.t("u").to(dev))
+    torch.cuda.synchronize()
+    assert tuple(logits.shape) == (m["B"], max(lengths), m["V"])
+    if dt == 0:
+        close(logits, g.t("logits"), rtol=1e-4, atol_scale=1e-5, what="teacher-forced logits")
+        close(probs, g.t("probs"), rtol=1e-4, atol_scale=1e-5, what="teacher-forced probs")
+        close(h_n, g.t("h_n"), rtol=1e-4, atol_scale=1e-5, what="h_n")
+        close(c_n, g.t("c_n"), rtol=1e-4, atol_scale=1e-5, what="c_n")
+        assert torch.equal(h_n, h2) and torch.equal(c_n, c2)
+    else:
+        assert rel_l2(logits.float(), g.t("logits")) < 2e-2 and rel_l2(probs.float(), g.t("probs")) < 3e-2
+        assert rel_l2(h_n, g.t("h_n")) < 2e-2 and rel_l2(c_n, g.t("c_n")) < 2e-2
+    # the module surface: Decoder.forward through the host class
+    from gan_image_captioning_amd.args import default_args
+    from gan_image_captioning_amd.generator import Decoder
+    args = default_args(vocab_size=m["V"], gen_embed_dim=m["E"], gen_hidden_dim=m["H"], gen_num_layers=m["NL"], temperature=1,
+                        compute_dtype="fp32" if dt == 0 else "bf16", device="cuda")
+    dec = Decoder(args).to(dev)
+    with torch.no_grad():
+        for n, p in zip(dec_param_names(m["NL"]), dec.param_list()):
+            p.copy_(gp[n])
+    dec.temperature = m["T"]
+    pred, (hn3, cn3) = dec(feats, caps, torch.tensor(lengths), pretrain=True)
+    torch.cuda.synchronize()
+    assert torch.equal(pred, logits) and torch.equal(hn3, h_n)
+
+
 def test_decoder_philox_noise_statistics(E, dev):
     """On-device Philox path: valid probabilities, ids in range, different seeds -> different samples."""
     g = Golden("cfg1")

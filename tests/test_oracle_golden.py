@@ -125,6 +125,24 @@ def test_pretrain_step_matches_reference():
             torch.testing.assert_close(gp[k], w, rtol=1e-4, atol=2e-5)
 
 
+def test_teacher_forced_forward_matches_reference():
+    """Decoder.forward (generator.py:39-53) of the reference, packed variable-length sequences, both modes."""
+    g = Golden("forward_tf_tiny")
+    m = g.meta
+    gp = g.group("gp0/")
+    lengths = [int(v) for v in g.t("lengths")]
+    logits, (h_n, c_n) = O.decoder_forward_tf(gp, g.t("feats"), g.t("caps"), lengths, m["T"], pretrain=True)
+    probs, _ = O.decoder_forward_tf(gp, g.t("feats"), g.t("caps"), lengths, m["T"], pretrain=False, u=g.t("u"))
+    torch.testing.assert_close(logits, g.t("logits"), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(probs, g.t("probs"), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(h_n, g.t("h_n"), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(c_n, g.t("c_n"), rtol=1e-5, atol=1e-6)
+    assert logits.shape[1] == max(lengths)
+    # padded positions see a zero LSTM output: the projection returns its bias there
+    b, t = 2, lengths[2]
+    torch.testing.assert_close(logits[b, t], gp["decoder.linear.bias"], rtol=1e-6, atol=1e-7)
+
+
 def test_losses_and_temperature_scalars():
     g = Golden("scalars")
     d_r, d_f, g_o = g.t("d_real"), g.t("d_fake"), g.t("g_out")
