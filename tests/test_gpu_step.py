@@ -196,3 +196,43 @@ def test_multi_step_training_runs_and_updates(tmp_path):
     assert all(torch.isfinite(torch.tensor(v)).all() for v in vals)
     assert int(inst.gen_opt.step_count) == 4 and int(inst.disc_opt.step_count) == 4
     assert not torch.equal(before, inst.gen_arena.flat)
+
+
+def test_bf16_step_at_bench_scale_close_to_oracle():
+    """The benchmark's own shapes (B=64, L=20, V=10000, E=H=512, R=64, F=900; --conditional-gan 0 so that the CPU oracle finishes in
+    seconds): the kernels that only engage at this scale (8-wave highway products, split-K gradients, shared D forward, stream
+    overlap) against one fp32 oracle step on the same weights, noise and dropout masks."""
+    from oracle import cpu_step as O
+    from tests.gpu_util import dec_param_names, disc_param_names
+    m = dict(B=64, L=20, V=10000, E=512, H=512, NL=1, De=64, R=64, fs=[3, 4, 5], nf=[300, 300, 300], loss="standard", clip=5.0,
+             gen_lr=1e-4, disc_lr=1e-4, T0=100, adapt="exp", adv_epochs=30)
+    g = torch.Generator().manual_seed(99)
+    gp = O.make_gen_params(m["V"], m["E"], m["H"], m["NL"], g)
+    dp = O.make_disc_params(m["V"], g)
+    caps = O.make_captions(m["B"], m["L"], m["V"], g)
+    us, masks = O.make_noise(m["B"], m["L"], m["V"], 900, m["R"], g)
+    T = 1.7
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = O.adv_step(dict(gp), dict(dp), caps, us, masks, T, "standard", 5.0, None, None)
+    inst, args = make_instructor(m, "fused", dtype="bf16")
+    dev = args.device
+    load_params(inst, gp, dp)
+    inst.gen.train(); inst.disc.train()
+    inst.gen.decoder.temperature = T
+    out = inst.fused(None, caps.to(dev), m["L"], True, torch.stack(us).to(dev), [k.to(dev) for k in masks], opt_step=False)
+    torch.cuda.synchronize()
+    match = float((out["ids"].cpu() == ref["ids"]).float().mean())
+    print(f"bench-scale bf16 id match-rate vs fp32 oracle: {match:.3f}")
+    assert match >= 0.9
+    assert float(out["losses"][1]) == pytest.approx(ref["d_loss"], rel=2e-2)
+    assert float(out["losses"][0]) == pytest.approx(ref["g_loss"], rel=3e-2)
+    from tests.gpu_util import rel_l2
+    dgot = {n: p.grad for n, p in zip(disc_param_names(3), inst.disc.param_list())}
+    for n in ("highway.weight", "feature2out.weight", "out2logits.weight", "embeddings.weight"):
+        err = rel_l2(dgot[n], ref["d_grads_raw"][n])
+        assert err < 8e-2, f"{n}: rel L2 {err}"
+    if match == 1.0:        # G's gradient flows through the sampled trajectory: comparable only if it is the same one
+        ggot = {n: p.grad for n, p in zip(dec_param_names(1), inst.gen.decoder.param_list())}
+        for n in ("decoder.linear.weight", "decoder.lstm.weight_hh_l0"):
+            err = rel_l2(ggot[n], ref["g_grads_raw"][n])
+            assert err < 8e-2, f"{n}: rel L2 {err}"
