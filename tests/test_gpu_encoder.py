@@ -77,6 +77,44 @@ def test_conv2d_matches_torch(dev, case, dtype):
     close(stats[Co:], s2, rtol=1e-3, what="bn sumsq")
 
 
+def test_trunk_forward_bf16_at_bench_resolution(dev, monkeypatch):
+    """ResNet-50 at 224x224, 16 images: the grids of the benchmark's layers (1-, 2- and 4-stage rings, ring-less shallow-K launches,
+    BatchNorm on load in every conv3, per-layer replica counts) against the fp32 CPU restatement; graph replay equals eager launches;
+    the running statistics move the same way."""
+    from gan_image_captioning_amd.trunk import ResNetTrunk
+    g = torch.Generator().manual_seed(18)
+    tp = OE.make_trunk_params("resnet50", g)
+    images = torch.randn(16, 3, 224, 224, generator=g)
+    running = {}                                                               # fresh buffers: mean 0, variance 1
+    for _n, _ci, co, _k, _s, _p in OE.layer_specs("resnet50"):
+        b = "encoder.resnet." + OE.bn_name(_n)
+        running[b + ".running_mean"] = torch.zeros(co)
+        running[b + ".running_var"] = torch.ones(co)
+    want = OE.trunk_forward(tp, images, "resnet50", training=True, running=running)
+    trunk = ResNetTrunk("resnet50")
+    trunk.load_state_dict({k[len("encoder.resnet."):]: v for k, v in tp.items()}, strict=False)
+    trunk = trunk.to(dev).train()
+    x = images.to(dev)
+    f1 = trunk(x, 1).float().clone()          # eager (first call)
+    f2 = trunk(x, 1).float().clone()          # captures the hipGraph and replays it
+    f3 = trunk(x, 1).float().clone()          # replay
+    torch.cuda.synchronize()
+    err = rel_l2(f1, want)
+    print(f"bf16 resnet50 @224 trunk rel-L2 error vs fp32 oracle: {err:.3e}")
+    assert err < 5e-2
+    assert rel_l2(f2, f1) < 2e-2 and rel_l2(f3, f1) < 2e-2        # BatchNorm sums are f32 atomics: not bit-reproducible
+    plan = trunk._plan
+    assert sum(1 for s in plan.steps if s.fused_in) == 16 and len(plan._graphs) == 1
+    sd = trunk.state_dict()
+    assert int(sd["1.num_batches_tracked"]) == 3
+    # three identical batches with momentum 0.1 from (mean 0, var 1): running = (1 - 0.9^3) * batch statistic (+ 0.9^3 for the variance)
+    got_m, got_v = sd["4.0.bn1.running_mean"].float().cpu(), sd["4.0.bn1.running_var"].float().cpu()
+    bm = running["encoder.resnet.4.0.bn1.running_mean"] / 0.1                      # the oracle updated fresh buffers once
+    bv = (running["encoder.resnet.4.0.bn1.running_var"] - 0.9) / 0.1
+    assert rel_l2(got_m, bm * (1 - 0.9 ** 3)) < 2e-2
+    assert rel_l2(got_v, bv * (1 - 0.9 ** 3) + 0.9 ** 3) < 2e-2
+
+
 @pytest.mark.parametrize("arch,S,N", [("resnet18", 64, 4), ("resnet50", 64, 2), ("resnet18", 96, 2)])
 def test_trunk_forward_f32_matches_oracle(dev, arch, S, N):
     from gan_image_captioning_amd.trunk import ResNetTrunk
