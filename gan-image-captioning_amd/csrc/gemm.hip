@@ -1059,7 +1059,8 @@ int launch(const GemmDesc& d, hipStream_t stream) {
   // per CU) and K is deep; with many blocks per CU the register-staged kernel wins (2 co-resident blocks, 72 KB LDS each)
   // and for K of one or two tiles the ring's prologue is pure overhead.  Measured on MI355X (tools/gemm_bench.py).
   constexpr bool CAN_PIPE = AKC && BKC && VEC;
-  const bool pipe = CAN_PIPE && per >= 6 && (long)tiles * splits <= 2 * 256 + 8 && !getenv("GIC_GEMM_NO_PIPE");
+  static const bool no_pipe = getenv("GIC_GEMM_NO_PIPE") != nullptr;
+  const bool pipe = CAN_PIPE && per >= 6 && (long)tiles * splits <= 2 * 256 + 8 && !no_pipe;
   if constexpr (CAN_PIPE) {
     if (pipe) {
       hipLaunchKernelGGL((gemm_kernel<TI, TO, AKC, BKC, BM, BN, VEC, EPI, CONV, true>), dim3(tiles, splits), dim3(256), 0, stream, d, per);
