@@ -555,7 +555,19 @@ int disc_bwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
   GIC_CHECK_LAUNCH("disc_conv_pool_bwd_x");
   // 5. embedding backward
   if (G) {
-    if (inp_ids) {
+    if (inp_ids && inp_soft) {
+      // mixed batch (one backward for the step's real and fake passes): the first half of the captions came in as token ids,
+      // the second half as soft rows; the gathered half scatters first (G->emb zeroed above or accumulated into)
+      const long half = c.rowsBL / 2;
+      hipLaunchKernelGGL(disc_emb_scatter_kernel, dim3(grid1d(half * c.De)), dim3(256), 0, stream, (const float*)nullptr,
+                         (const void*)ws->demb, c.dt, inp_ids, G->emb, half, c.De, c.V);
+      GIC_CHECK_LAUNCH("disc_emb_scatter");
+      GemmDesc w;   // dW_emb[De, V] += demb[half:]^T inp
+      w.A = (const char*)ws->demb + (size_t)half * c.De * dtype_size(c.dt); w.lda = c.De; w.a_kc = 0; w.B = inp_soft; w.ldb = ld_inp; w.b_kc = 0;
+      w.C = G->emb; w.ldc = c.V;
+      w.M = c.De; w.N = c.V; w.K = (int)half; w.in_dtype = c.dt; w.out_dtype = DT_F32; w.accumulate = 1;
+      GIC_PROPAGATE(gemm(w, stream));
+    } else if (inp_ids) {
       hipLaunchKernelGGL(disc_emb_scatter_kernel, dim3(grid1d(c.rowsBL * c.De)), dim3(256), 0, stream, (const float*)nullptr,
                          (const void*)ws->demb, c.dt, inp_ids, G->emb, c.rowsBL, c.De, c.V);
       GIC_CHECK_LAUNCH("disc_emb_scatter");
@@ -632,7 +644,8 @@ int gic_disc_bwd(const gic_disc_dims* dims, const gic_disc_params* P, const gic_
   DCtx c;
   GIC_PROPAGATE(make_ctx(dims, P, G, c));
   GIC_CHECK_ARG(P && S && st && ws && d_logits, "disc_bwd: null argument");
-  GIC_CHECK_ARG((inp_soft != nullptr) != (inp_ids != nullptr), "disc_bwd: pass exactly one of inp_soft / inp_ids");
+  GIC_CHECK_ARG(inp_soft || inp_ids, "disc_bwd: pass inp_soft, inp_ids, or both (mixed batch: ids for the first B/2 captions)");
+  GIC_CHECK_ARG(!(inp_soft && inp_ids) || (G && !d_inp && c.B % 2 == 0), "disc_bwd: a mixed batch needs an even B, grads and no d_inp");
   GIC_CHECK_ARG(ws->dfeat && ws->dh && ws->dydrop && ws->dpooled && ws->demb, "disc_bwd: null workspace buffer");
   GIC_CHECK_ARG(!d_inp || (inp_soft && ld_dinp >= c.V), "disc_bwd: d_inp needs a soft input and ld_dinp >= V");
   if (G) {

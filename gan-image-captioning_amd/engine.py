@@ -111,7 +111,8 @@ def gan_losses(loss_type: str, d_real, d_fake, g_out, want_grads: bool = True):
     g = None
     if want_grads:
         buf = torch.empty(5, n, device=d_real.device, dtype=torch.float32)
-        g = {"dd_real": buf[0], "dd_fake": buf[1], "dg_out": buf[2], "dg_real": buf[3], "dg_fake": buf[4]}
+        g = {"dd_real": buf[0], "dd_fake": buf[1], "dg_out": buf[2], "dg_real": buf[3], "dg_fake": buf[4],
+             "dd_real_fake": buf[:2].view(-1)}          # [real ; fake] contiguous: one backward over both passes
     L.check(L.load().gic_gan_losses(L.LOSS_TYPES[loss_type], ptr(d_real), ptr(d_fake), ptr(g_out), n, ptr(losses),
                                     ptr(g["dd_real"]) if g else None, ptr(g["dd_fake"]) if g else None,
                                     ptr(g["dg_out"]) if g else None, ptr(g["dg_real"]) if g else None,
@@ -506,10 +507,24 @@ class DiscEngine:
             stream_ptr()), "gic_disc_fwd_redrop")
         return logits, dst_state
 
+    def split_state(self, st: dict):
+        """Views of the first / second half of a state's rows (two forward passes of B/2 captions each written into one state)."""
+        a, b = {}, {}
+        for k, v in st.items():
+            h = v.shape[0] // 2
+            a[k], b[k] = v[:h], v[h:]
+        return a, b
+
     def bwd(self, params, st, inp_soft, inp_ids, train: bool, d_logits: torch.Tensor, want_param_grads: bool,
             want_input_grad: bool, grads=None, accumulate: bool = False, ws=None, d_inp=None):
+        """Both ``inp_soft`` and ``inp_ids`` given: mixed batch (gicap.h) -- ``st`` holds the ids pass in its first half of the rows
+        and the soft pass in its second half; one backward serves both."""
         src = inp_soft if inp_soft is not None else inp_ids
         B, Lc = src.shape[0], src.shape[1]
+        if inp_soft is not None and inp_ids is not None:
+            if inp_soft.shape[:2] != inp_ids.shape[:2] or want_input_grad or not want_param_grads:
+                raise ValueError("mixed batch: equal halves, parameter gradients only")
+            B *= 2
         dev = src.device
         d_logits = d_logits.contiguous().float()
         self.prepare(params)

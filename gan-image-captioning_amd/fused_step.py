@@ -55,11 +55,12 @@ class FusedAdvStep:
                 "ids": torch.empty(B, L, device=dev, dtype=torch.int64),
                 "d_feat": torch.empty(B, dec.E, device=dev, dtype=torch.float32),
                 "d_probs": torch.empty(B, L, dec.V, device=dev, dtype=dec.act),
-                "st_real": den.alloc_state(B, L, dev), "st_fake": den.alloc_state(B, L, dev),
-                "disc_ws": den.alloc_bwd_ws(B, L, dev), "disc_ws_gen": den.alloc_bwd_ws(B, L, dev),
+                "st_rf": den.alloc_state(2 * B, L, dev),      # D(real) | D(fake) in the two halves: ONE backward over both
+                "disc_ws": den.alloc_bwd_ws(2 * B, L, dev), "disc_ws_gen": den.alloc_bwd_ws(B, L, dev),
                 "logits": torch.empty(3, B * den.R, device=dev, dtype=torch.float32),
                 "ones": torch.ones(B, device=dev, dtype=torch.int64),
             }
+            self._buf[key]["st_real"], self._buf[key]["st_fake"] = den.split_state(self._buf[key]["st_rf"])
             # D(gen) sees the same input as D(fake) (training.py:163-164): it shares everything up to the dropout draw
             self._buf[key]["st_gen"] = den.shared_state(self._buf[key]["st_fake"], B, L, dev)
         return self._buf[key]
@@ -199,10 +200,15 @@ class FusedAdvStep:
 
         # ---- D path on the main stream: d_loss -> D parameters (training.py:168), then D's clip + Adam
         self.disc_arena.grad.zero_()          # ONE fill; both passes accumulate (instead of a fill per small gradient tensor)
-        self.den.bwd(dparams, buf["st_real"], real_soft, real_ids, d_train, lgrads["dd_real"], True, False,
-                     grads=d_grads, accumulate=True, ws=buf["disc_ws"])
-        self.den.bwd(dparams, buf["st_fake"], probs, None, d_train, lgrads["dd_fake"], True, False,
-                     grads=d_grads, accumulate=True, ws=buf["disc_ws"])
+        if real_ids is not None:                # real (ids) and fake (soft) passes differentiated as one batch of 2B captions
+            self.den.bwd(dparams, buf["st_rf"], probs, real_ids, d_train, lgrads["dd_real_fake"], True, False,
+                         grads=d_grads, accumulate=True, ws=buf["disc_ws"])
+        else:                                   # --real-as-ids 0: two dense passes
+            half_ws = {k: v[:v.shape[0] // 2] for k, v in buf["disc_ws"].items()}
+            self.den.bwd(dparams, buf["st_real"], real_soft, None, d_train, lgrads["dd_real"], True, False,
+                         grads=d_grads, accumulate=True, ws=half_ws)
+            self.den.bwd(dparams, buf["st_fake"], probs, None, d_train, lgrads["dd_fake"], True, False,
+                         grads=d_grads, accumulate=True, ws=half_ws)
         if self.reducer is not None:
             # collectives run one after the other on the reducer's stream, in the order they become ready:
             # G's early bucket (above), D's arena (now), the rest of G's arena (when the G path is through)

@@ -231,7 +231,11 @@ int gic_disc_fwd_redrop(const gic_disc_dims* dims, const gic_disc_params* params
                         uint64_t seed, float* logits, void* stream);
 
 /* d_logits f32 [B*R].  grads may be NULL (no parameter gradients wanted: the generator's path,
- * training.py:169).  d_inp: act [B*L, V] (row stride ld_dinp) or NULL. */
+ * training.py:169).  d_inp: act [B*L, V] (row stride ld_dinp) or NULL.
+ * Exactly one of inp_soft / inp_ids describes the input of the forward(s) that filled `state` -- or BOTH, for a state whose first
+ * B/2 captions were evaluated from token ids (inp_ids: int64 [B/2, L]) and whose last B/2 from soft rows (inp_soft: act
+ * [B/2*L, V]): the step's D(real) and D(fake) passes written into the two halves of one state, differentiated in one call
+ * (grads required, d_inp must be NULL). */
 int gic_disc_bwd(const gic_disc_dims* dims, const gic_disc_params* params, const gic_disc_shadow* shadow,
                  const gic_disc_state* state, const gic_disc_bwd_ws* ws, const void* inp_soft, int64_t ld_inp,
                  const int64_t* inp_ids, int train, const float* d_logits, const gic_disc_grads* grads,
