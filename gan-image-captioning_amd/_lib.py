@@ -92,6 +92,10 @@ _SIGNATURES = {
     "gic_gemm": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64,
                            C.c_int, C.c_int, C.c_int, C.c_int, c_void_p, C.c_int, C.c_float, c_void_p]),
     "gic_cast2d": (C.c_int, [c_void_p, C.c_int, C.c_int64, c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, c_void_p]),
+    "gic_decoder_state_bytes": (C.c_int, [_P(DecoderDims), c_void_p]),
+    "gic_decoder_bwd_ws_bytes": (C.c_int, [_P(DecoderDims), c_void_p]),
+    "gic_disc_state_bytes": (C.c_int, [_P(DiscDims), c_void_p]),
+    "gic_disc_bwd_ws_bytes": (C.c_int, [_P(DiscDims), c_void_p]),
     "gic_decoder_prepare": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), c_void_p]),
     "gic_decoder_sample_fwd": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), _P(DecoderState), c_void_p,
                                          c_void_p, C.c_uint64, C.c_float, C.c_int, c_void_p, c_void_p, c_void_p]),

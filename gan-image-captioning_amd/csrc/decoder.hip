@@ -547,6 +547,39 @@ int gic_decoder_forward_tf(const gic_decoder_dims* dims, const gic_decoder_param
                               h_n, c_n, (hipStream_t)stream);
 }
 
+int gic_decoder_state_bytes(const gic_decoder_dims* dims, uint64_t* out) {
+  Ctx c;
+  GIC_PROPAGATE(check_dims(dims, c));
+  GIC_CHECK_ARG(out, "decoder_state_bytes: null out");
+  const uint64_t B = c.B, L = c.L, H = c.H, a = c.asz();
+  for (int l = 0; l < GIC_MAX_LAYERS; ++l) {
+    const bool on = l < c.NL;
+    out[l] = on ? (L + 1) * B * (uint64_t)c.ldx(l) * a : 0;
+    out[GIC_MAX_LAYERS + l] = on ? L * B * 4 * H * 4 : 0;
+    out[2 * GIC_MAX_LAYERS + l] = on ? (L + 1) * B * H * 4 : 0;
+  }
+  out[3 * GIC_MAX_LAYERS + 0] = B * L * H * a;
+  out[3 * GIC_MAX_LAYERS + 1] = B * (uint64_t)c.V * 4;
+  out[3 * GIC_MAX_LAYERS + 2] = B * 4 * H * 4;
+  return GIC_OK;
+}
+
+int gic_decoder_bwd_ws_bytes(const gic_decoder_dims* dims, uint64_t* out) {
+  Ctx c;
+  GIC_PROPAGATE(check_dims(dims, c));
+  GIC_CHECK_ARG(out, "decoder_bwd_ws_bytes: null out");
+  const uint64_t B = c.B, L = c.L, H = c.H, a = c.asz();
+  out[0] = B * L * (uint64_t)c.V * a;
+  out[1] = B * L * H * 4;
+  for (int l = 0; l < GIC_MAX_LAYERS; ++l) {
+    const bool on = l < c.NL;
+    out[2 + l] = on ? L * B * 4 * H * a : 0;
+    out[2 + GIC_MAX_LAYERS + l] = on ? (L + 1) * B * (uint64_t)c.ldx(l) * 4 : 0;
+    out[2 + 2 * GIC_MAX_LAYERS + l] = on ? B * H * 4 : 0;
+  }
+  return GIC_OK;
+}
+
 int gic_decoder_prepare(const gic_decoder_dims* dims, const gic_decoder_params* P, const gic_decoder_shadow* S, void* stream_) {
   Ctx c;
   GIC_PROPAGATE(check_dims(dims, c));

@@ -594,6 +594,34 @@ using namespace gic;
 
 extern "C" {
 
+int gic_disc_state_bytes(const gic_disc_dims* dims, uint64_t* out) {
+  DCtx c;
+  GIC_PROPAGATE(make_ctx(dims, nullptr, nullptr, c));
+  GIC_CHECK_ARG(out, "disc_state_bytes: null out");
+  const uint64_t a = dtype_size(c.dt), MR = c.rowsBR, Fp = c.Fp;
+  out[0] = (uint64_t)c.rowsBL * c.De * 4;      // emb
+  out[1] = MR * Fp * a;                        // pooled
+  out[2] = MR * Fp;                            // argmax
+  out[3] = MR * Fp * 4;                        // hpre
+  out[4] = MR * Fp;                            // keep
+  out[5] = MR * Fp * a;                        // ydrop
+  out[6] = MR * kOutDim * 4;                   // feat
+  return GIC_OK;
+}
+
+int gic_disc_bwd_ws_bytes(const gic_disc_dims* dims, uint64_t* out) {
+  DCtx c;
+  GIC_PROPAGATE(make_ctx(dims, nullptr, nullptr, c));
+  GIC_CHECK_ARG(out, "disc_bwd_ws_bytes: null out");
+  const uint64_t a = dtype_size(c.dt), MR = c.rowsBR, Fp = c.Fp;
+  out[0] = MR * kOutPad * a;                   // dfeat
+  out[1] = MR * Fp * a;                        // dh
+  out[2] = MR * Fp * 4;                        // dydrop
+  out[3] = MR * Fp * 4;                        // dpooled
+  out[4] = (uint64_t)c.rowsBL * c.De * a;      // demb
+  return GIC_OK;
+}
+
 // shadow.emb [De,V]; shadow.hw_w [Fp,Fp] and shadow.f2o_w [104,Fp] zero-padded images of highway / feature2out
 int gic_disc_prepare(const gic_disc_dims* dims, const gic_disc_params* P, const gic_disc_shadow* S, void* stream_) {
   DCtx c;

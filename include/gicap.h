@@ -118,6 +118,12 @@ typedef struct gic_decoder_bwd_ws {      /* scratch for backward (caller-owned) 
   float* dc[GIC_MAX_LAYERS];             /* [B, H] */
 } gic_decoder_bwd_ws;
 
+/* Byte size of every buffer of the caller-owned structs above for `dims`, in field order (per-layer arrays take GIC_MAX_LAYERS
+ * entries, 0 for unused layers): gic_decoder_state -> xh[], gates[], c[], hout, logits, gpre (3*GIC_MAX_LAYERS + 3 values);
+ * gic_decoder_bwd_ws -> dlogits, dhout, dgates[], dxh[], dc[] (2 + 3*GIC_MAX_LAYERS values).  Host-only: no GPU needed. */
+int gic_decoder_state_bytes(const gic_decoder_dims* dims, uint64_t* out);
+int gic_decoder_bwd_ws_bytes(const gic_decoder_dims* dims, uint64_t* out);
+
 int gic_decoder_prepare(const gic_decoder_dims* dims, const gic_decoder_params* params,
                         const gic_decoder_shadow* shadow, void* stream);
 
@@ -209,8 +215,13 @@ typedef struct gic_disc_bwd_ws {
   void* dh;                              /* act [B*R, Fp] */
   float* dydrop;                         /* [B*R, Fp] */
   float* dpooled;                        /* [B*R, Fp] */
-  float* demb;                           /* [B*L, De] */
+  void* demb;                            /* act [B*L, De] */
 } gic_disc_bwd_ws;
+
+/* Byte sizes in field order: gic_disc_state -> emb, pooled, argmax, hpre, keep, ydrop, feat (7 values; ydrop must start zeroed:
+ * its pad columns are read); gic_disc_bwd_ws -> dfeat, dh, dydrop, dpooled, demb (5 values).  Host-only. */
+int gic_disc_state_bytes(const gic_disc_dims* dims, uint64_t* out);
+int gic_disc_bwd_ws_bytes(const gic_disc_dims* dims, uint64_t* out);
 
 int gic_disc_prepare(const gic_disc_dims* dims, const gic_disc_params* params, const gic_disc_shadow* shadow, void* stream);
 

@@ -58,3 +58,37 @@ def test_cpu_tensors_are_refused():
     from gan_image_captioning_amd._lib import GicError
     with pytest.raises(GicError):
         engine.embedding_fwd(torch.zeros(4, 4), torch.zeros(2, dtype=torch.long))
+
+
+def test_workspace_size_queries_match_the_host_allocations():
+    """gic_*_bytes (host-only) against the buffers the Python engines allocate (on the meta device: shapes only)."""
+    import torch
+    from gan_image_captioning_amd import _lib, engine
+    lib = _lib.load()
+    ML = _lib.MAX_LAYERS
+    for dt in (0, 1):
+        B, Lc, V, E, H, NL = 6, 9, 70, 24, 32, 2
+        dec = engine.DecoderEngine(V, E, H, NL, dt)
+        st, ws = dec.alloc_state(B, Lc, "meta"), dec.alloc_bwd_ws(B, Lc, "meta")
+        nb = lambda t: t.numel() * t.element_size()
+        d = dec.dims(B, Lc)
+        out = (ctypes.c_uint64 * (3 * ML + 3))()
+        assert lib.gic_decoder_state_bytes(ctypes.byref(d), out) == 0
+        want = [nb(t) for t in st["xh"]] + [0] * (ML - NL) + [nb(t) for t in st["gates"]] + [0] * (ML - NL) + \
+               [nb(t) for t in st["c"]] + [0] * (ML - NL) + [nb(st["hout"]), nb(st["logits"]), nb(st["gpre"])]
+        assert list(out) == want
+        out = (ctypes.c_uint64 * (2 + 3 * ML))()
+        assert lib.gic_decoder_bwd_ws_bytes(ctypes.byref(d), out) == 0
+        want = [nb(ws["dlogits"]), nb(ws["dhout"])] + [nb(t) for t in ws["dgates"]] + [0] * (ML - NL) + \
+               [nb(t) for t in ws["dxh"]] + [0] * (ML - NL) + [nb(t) for t in ws["dc"]] + [0] * (ML - NL)
+        assert list(out) == want
+        den = engine.DiscEngine(V, 64, 64, [3, 4, 5], [300, 300, 300], dt)
+        st, ws = den.alloc_state(B, Lc, "meta"), den.alloc_bwd_ws(B, Lc, "meta")
+        dd = den.dims(B, Lc)
+        out = (ctypes.c_uint64 * 7)()
+        assert lib.gic_disc_state_bytes(ctypes.byref(dd), out) == 0
+        assert list(out) == [nb(st[k]) for k in ("emb", "pooled", "argmax", "hpre", "keep", "ydrop", "feat")]
+        out = (ctypes.c_uint64 * 5)()
+        assert lib.gic_disc_bwd_ws_bytes(ctypes.byref(dd), out) == 0
+        assert list(out) == [nb(ws[k]) for k in ("dfeat", "dh", "dydrop", "dpooled", "demb")]
+    assert lib.gic_decoder_state_bytes(None, None) == -1
