@@ -49,7 +49,7 @@ def parse():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--step-impl", default="fused", choices=["fused", "autograd"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-steps", type=int, default=2)
+    p.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-oracle steps per leg (after one warm-up)")
     p.add_argument("--no-prefetch", action="store_true", help="do not hand the next batch's images to the step (no trunk prefetch)")
     return p.parse_args()
 
@@ -89,20 +89,47 @@ def event_time_ms(fn, iters, stream):
     return start.elapsed_time(stop) / iters
 
 
-def roofline_probe(inst, args, cgan):
-    """Replay the kernel that dominates the step (rocprofv3 --stats, profiles/) with its step shapes."""
+def conv_times_in_step(inst, step, n_steps=4):
+    """HIP events around EVERY trunk convolution launch, on its launch stream, while real train steps run: the trunk pass of the
+    next batch is issued as eager launches (no hipGraph: graph nodes cannot carry per-kernel events) on the look-ahead stream
+    under the step, as in the timed region.  Returns {layer name: [ms, ...]}."""
+    plan = inst.gen.encoder.resnet._plan
+    was = plan.use_graph
+    plan.use_graph = False
+    for k in range(2):
+        step(k)
+    torch.cuda.synchronize()
+    plan.conv_trace = []
+    for k in range(n_steps):
+        step(k)
+    torch.cuda.synchronize()
+    trace, plan.conv_trace = plan.conv_trace, None
+    plan.use_graph = was
+    out = {}
+    for name, a, b in trace:
+        out.setdefault(name, []).append(a.elapsed_time(b))
+    return out
+
+
+def roofline_probe(inst, args, cgan, step=None):
+    """The kernel family that dominates the step (rocprofv3 --stats, profiles/): in-step HIP-event timing + an isolated replay."""
     from gan_image_captioning_amd import engine
     stream = torch.cuda.current_stream()
     dev = args.device
     if cgan:
         from gan_image_captioning_amd import encoder_engine
         traffic = None
-        try:     # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json; see its "source")
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+        try:     # HBM bytes per launch: NOT measured by this run -- read from the committed rocprofv3 --pmc passes of this command
+            name = "r02_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) else "r01_pmc_traffic.json"
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
                 traffic = json.load(fh)["conv_bnstats"]["hbm_bytes_per_launch"]
         except Exception:
-            pass
-        return encoder_engine.roofline_probe(inst.gen.encoder, args, event_time_ms, MFMA_BF16_PEAK_TFLOPS, traffic)
+            name = None
+        in_step = conv_times_in_step(inst, step) if step is not None else None
+        r = encoder_engine.roofline_probe(inst.gen.encoder, args, event_time_ms, MFMA_BF16_PEAK_TFLOPS, traffic, in_step)
+        r["traffic_source"] = (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; "
+                               "not re-measured by this run") if traffic is not None else None
+        return r
     # discriminator highway GEMM: [B*64, 904] x [900, 904]^T, bf16 MFMA, fused gate+dropout epilogue is separate;
     # the plain GEMM of the same shape is the dominant launch without the encoder.
     den = inst.disc.engine()
@@ -119,11 +146,14 @@ def roofline_probe(inst, args, cgan):
 
 
 def cpu_baseline(a, cgan):
-    """The CPU oracle on a bounded sample of the same workload: `cpu_steps` full steps at the same batch."""
+    """The CPU oracle on a bounded sample of the same workload: `cpu_steps` full steps at the same batch, median; with the
+    encoder in the step (the headline workload) and without it (the part the reference itself owns: torchvision's trunk is not in
+    the reference tree)."""
     from oracle import cpu_step as O
     # host cores actually usable here: the affinity mask, capped at the 16-core share of a 1-GPU box
     cores = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(cores)
+    import statistics
     g = torch.Generator().manual_seed(1008)
     B, L, V = a.batch, CFG2["L"], CFG2["V"]
     feat_dim = None
@@ -139,29 +169,56 @@ def cpu_baseline(a, cgan):
     if cgan:
         tp = OE.make_trunk_params(a.encoder, g)
         images = torch.randn(B, 3, CFG2["S"], CFG2["S"], generator=g)
-    times = []
+    times, times_noenc = [], []
     for i in range(1 + a.cpu_steps):
         log(f"cpu_baseline step {i}")
         t0 = time.perf_counter()
         if cgan:
             with torch.no_grad():
                 trunk_feat = OE.trunk_forward(tp, images, a.encoder)
+        t1 = time.perf_counter()
         O.adv_step(gp, dp, caps, us, masks, 1.5, "standard", 5.0, gopt, dopt, trunk_feat=trunk_feat)
-        times.append(time.perf_counter() - t0)
-    t = sum(times[1:]) / max(1, len(times) - 1)
-    return {"value": round(B / t, 2), "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{a.cpu_steps} full steps (after 1 warm-up) of the same batch={B} workload, fp32, oracle/cpu_step.py"
-                      + (" + oracle/cpu_encoder.py trunk" if cgan else ""),
-            "ms_per_step": round(t * 1e3, 1)}
+        t2 = time.perf_counter()
+        times.append(t2 - t0)
+        times_noenc.append(t2 - t1)
+    t = statistics.median(times[1:])
+    tn = statistics.median(times_noenc[1:])
+    out = {"value": round(B / t, 2), "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"median of {a.cpu_steps} full steps (after 1 warm-up) of the same batch={B} workload, fp32, oracle/cpu_step.py"
+                     + (" + oracle/cpu_encoder.py trunk" if cgan else ""),
+           "ms_per_step": round(t * 1e3, 1)}
+    if cgan:
+        out["without_encoder"] = {"value": round(B / tn, 2), "ms_per_step": round(tn * 1e3, 1),
+                                  "note": "the same steps minus the trunk forward: generator + discriminator + optimizers only "
+                                          "(the part of the path the reference's own files define)"}
+    return out
+
+
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` outside torchrun: start one rank per GPU as a FRESH child process tree
+    (`python -m torch.distributed.run ...`, rendezvous on 127.0.0.1) before this process touches the GPU, relay rank 0's JSON
+    line and exit with the child's code.  No exec, nothing after GPU initialisation."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this host driver (RCCL across processes)
+    log("launching " + " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus} (or without torchrun)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     import importlib
@@ -215,7 +272,7 @@ def main():
                    "parallelism": "dp%d" % world},
     }
     log(f"timed region done: {elapsed / a.steps * 1e3:.3f} ms/step; roofline probe")
-    out["roofline"] = roofline_probe(inst, args, cgan)
+    out["roofline"] = roofline_probe(inst, args, cgan, step)
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, cgan)
     print(json.dumps(out), flush=True)

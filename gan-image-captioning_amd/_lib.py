@@ -54,7 +54,7 @@ class DecoderBwdWs(C.Structure):
 class DiscDims(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("V", C.c_int32), ("De", C.c_int32), ("R", C.c_int32),
                 ("nconv", C.c_int32), ("fsize", C.c_int32 * MAX_CONVS), ("nfilt", C.c_int32 * MAX_CONVS),
-                ("F", C.c_int32), ("Fp", C.c_int32), ("dtype", C.c_int32)]
+                ("F", C.c_int32), ("Fp", C.c_int32), ("dtype", C.c_int32), ("drop_p", C.c_float)]
 
 
 class DiscParams(C.Structure):

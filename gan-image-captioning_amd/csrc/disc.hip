@@ -333,7 +333,9 @@ __global__ void disc_highway_bwd_kernel(const float* __restrict__ dydrop, const 
 
 struct DCtx {
   int B, L, V, De, R, s, F, Fp, dt;
+  float drop_p;              // nn.Dropout p of discriminator.py:10,30
   long rowsBL, rowsBR;
+  float keep_scale(int train) const { return train ? 1.f / (1.f - drop_p) : 1.f; }
   ConvMeta cm;
 };
 
@@ -345,6 +347,8 @@ int make_ctx(const gic_disc_dims* d, const gic_disc_params* P, const gic_disc_gr
   GIC_CHECK_ARG(d->dtype == DT_F32 || d->dtype == DT_BF16, "disc: bad dtype");
   c.B = d->B; c.L = d->L; c.V = d->V; c.De = d->De; c.R = d->R; c.s = d->De / d->R; c.dt = d->dtype;
   c.F = d->F; c.Fp = d->Fp;
+  GIC_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f, "disc: dropout p=%g must be in [0, 1)", (double)d->drop_p);
+  c.drop_p = d->drop_p;
   c.rowsBL = (long)d->B * d->L; c.rowsBR = (long)d->B * d->R;
   GIC_CHECK_ARG(c.Fp >= c.F && c.Fp % 8 == 0, "disc: Fp=%d must be >= F=%d and a multiple of 8", c.Fp, c.F);
   GIC_CHECK_ARG(c.L <= 255, "disc: L=%d exceeds the uint8 argmax range", c.L);
@@ -413,8 +417,8 @@ int disc_fwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
     g.M = (int)c.rowsBR; g.N = c.F; g.K = c.Fp; g.in_dtype = c.dt; g.out_dtype = c.dt; g.bias = P->hw_b;
     g.epi = EPI_HIGHWAY; g.X = st->pooled; g.ldx = c.Fp; g.Hpre = st->hpre; g.ldh = c.Fp;
     if (train) {
-      g.keep_scale = 1.f / (1.f - 0.2f);     // nn.Dropout(0.2), discriminator.py:10,30
-      g.drop_p = 0.2f;
+      g.keep_scale = c.keep_scale(1);        // nn.Dropout(p), discriminator.py:10,30
+      g.drop_p = c.drop_p;
       if (keep_mask) { g.mask = keep_mask; g.ldmask = c.F; } else { g.use_philox = 1; g.seed = seed; g.stream = 0x44495343ull; }
       g.mask_out = st->keep; g.ldmask_out = c.Fp;
     }
@@ -464,7 +468,7 @@ int disc_fwd_redrop_t(const DCtx& c, const gic_disc_params* P, const gic_disc_sh
                       const gic_disc_state* dst, int train, const uint8_t* keep_mask, uint64_t seed, float* logits, hipStream_t stream) {
   const long groups = (c.rowsBR + 3) / 4;
   hipLaunchKernelGGL((disc_highway_redrop_kernel<TA>), dim3(grid1d(groups * c.F)), dim3(256), 0, stream, (const float*)src->hpre,
-                     (const TA*)src->pooled, keep_mask, train, seed, 0.2f, train ? 1.f / (1.f - 0.2f) : 1.f, (TA*)dst->ydrop,
+                     (const TA*)src->pooled, keep_mask, train, seed, c.drop_p, c.keep_scale(train), (TA*)dst->ydrop,
                      train ? dst->keep : nullptr, c.rowsBR, c.F, c.Fp);
   GIC_CHECK_LAUNCH("disc_highway_redrop");
   return disc_head_fwd(c, P, S, dst, logits, stream);
@@ -504,7 +508,7 @@ int disc_bwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
   }
   // 3. highway backward
   hipLaunchKernelGGL((disc_highway_bwd_kernel<TA>), dim3(grid1d(MR * c.Fp)), dim3(256), 0, stream, (const float*)ws->dydrop,
-                     train ? (const uint8_t*)st->keep : nullptr, train ? 1.f / (1.f - 0.2f) : 1.f, (const float*)st->hpre,
+                     train ? (const uint8_t*)st->keep : nullptr, c.keep_scale(train), (const float*)st->hpre,
                      (const TA*)st->pooled, (TA*)ws->dh, ws->dpooled, MR, c.F, c.Fp);
   GIC_CHECK_LAUNCH("disc_highway_bwd");
   {

@@ -88,9 +88,12 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const TA* __restrict__ l
   for (int v = threadIdx.x; v < V; v += 256) s += expf(to_f32<TA>(x[v]) - mx);
   s = block_sum(s, red);
   long tgt = targets[row];
-  tgt = tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt);
+  // nn.CrossEntropyLoss raises on a target outside [0, V) (training.py:81-83 has no ignore_index): no exception can cross a
+  // kernel, so such a row poisons the mean with NaN (the host loop raises on it) instead of silently training on a clamped label
+  const bool bad = tgt < 0 || tgt >= V;
+  tgt = bad ? 0 : tgt;
   const float lse = mx + logf(s);
-  if (threadIdx.x == 0) row_loss[row] = lse - to_f32<TA>(x[tgt]);
+  if (threadIdx.x == 0) row_loss[row] = bad ? NAN : lse - to_f32<TA>(x[tgt]);
   if (dlogits) {
     const float inv_rows = 1.f / (float)rows;
     for (int v = threadIdx.x; v < V; v += 256) {

@@ -57,8 +57,9 @@ class _ConvParams(nn.Module):
 class Discriminator(nn.Module):
     def __init__(self, args, gpu=False, dropout=0.2):
         super().__init__()
-        if dropout != 0.2:
-            raise NotImplementedError("the fused highway epilogue implements nn.Dropout(0.2) (discriminator.py:10)")
+        if not 0.0 <= float(dropout) < 1.0:            # nn.Dropout(dropout), discriminator.py:10,30 (p = 1 would zero every feature)
+            raise ValueError("dropout probability has to be in [0, 1), but got {}".format(dropout))
+        self.dropout_p = float(dropout)
         self.vocab_size = args.vocab_size
         self.embed_dim = args.disc_embed_dim
         self.padding_idx = args.padding_idx
@@ -80,7 +81,7 @@ class Discriminator(nn.Module):
         if self._engine is None:
             a = self.args
             self._engine = engine.DiscEngine(a.vocab_size, a.disc_embed_dim, a.disc_num_rep, a.disc_filter_sizes,
-                                             a.disc_num_filters, _compute_dtype(a))
+                                             a.disc_num_filters, _compute_dtype(a), dropout=self.dropout_p)
         return self._engine
 
     def param_list(self) -> List[nn.Parameter]:

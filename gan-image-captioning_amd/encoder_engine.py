@@ -67,6 +67,7 @@ class TrunkPlan:
         self._nrep = {}
         self.use_graph = not os.environ.get("GIC_NO_GRAPH")
         self.pending_tracked = 0
+        self.conv_trace = None      # measurement (bench.py): a list -> (layer name, start event, stop event) per convolution launch
 
     def sync_counters(self) -> None:
         """Fold the forward count into every BatchNorm's ``num_batches_tracked`` buffer (kept off the hot path)."""
@@ -98,6 +99,7 @@ class TrunkPlan:
         key = (N, S)
         if key in self._bufs:
             self._nrep = self._bufs[key]["nrep"]
+            self._running_table(self._bufs[key], dev)
             return self._bufs[key]
         act = self.act
         b: dict = {"stats": torch.zeros(self.stats_len, device=dev, dtype=torch.float32)}
@@ -142,7 +144,18 @@ class TrunkPlan:
         for s in self.steps:
             tiles = -(-rows[s.name] // 128) * -(-s.cout // 128)
             b["nrep"][s.name] = STATS_REPLICAS if tiles > 1024 else (mid if tiles > 256 else lo)
-        # device table for the one-launch running-statistics update
+        self._running_table(b, dev)
+        self._bufs[key] = b
+        self._nrep = b["nrep"]
+        return b
+
+    def _running_table(self, b: dict, dev) -> None:
+        """Device table for the one-launch running-statistics update.  It bakes in the BatchNorm buffers' addresses, so it is
+        rebuilt whenever they move (module .to() / .float() / load into new storage), like the graph key of _launch_trunk."""
+        key = tuple(t.data_ptr() for s in self.steps for t in (s.bn.running_mean, s.bn.running_var))
+        if b.get("table_key") == key:
+            return
+        rows = b["rows"]
         table = (L.BnRunningDesc * len(self.steps))()
         for i, s in enumerate(self.steps):
             table[i].stats = b["stats"].data_ptr() + 4 * s.stats_off
@@ -154,25 +167,44 @@ class TrunkPlan:
             table[i].nrep = b["nrep"][s.name]
         raw = bytes(table)
         b["table"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
-        self._bufs[key] = b
-        self._nrep = b["nrep"]
-        return b
+        b["table_key"] = key
 
     # ---------------------------------------------------------------- kernels
+    def _traced(self, name: str):
+        """Context that brackets ONE convolution launch with HIP events on its launch stream while ``conv_trace`` is a list."""
+        plan = self
+
+        class _T:
+            def __enter__(self_t):
+                if plan.conv_trace is not None:
+                    self_t.a = torch.cuda.Event(enable_timing=True)
+                    self_t.a.record(torch.cuda.current_stream())
+
+            def __exit__(self_t, *exc):
+                if plan.conv_trace is not None:
+                    b = torch.cuda.Event(enable_timing=True)
+                    b.record(torch.cuda.current_stream())
+                    plan.conv_trace.append((name, self_t.a, b))
+        return _T()
+
     def _conv(self, s: _ConvStep, x: torch.Tensor, y: torch.Tensor, stats: Optional[torch.Tensor], N, H, W, cin=None, kw=None, pad=None):
         st = None if stats is None else stats.data_ptr() + 4 * s.stats_off
-        _check(L.load().gic_conv2d(ptr(x), ptr(s.w), ptr(y), st, self._nrep[s.name], self.dtype, N, H, W, cin if cin is not None else s.cin, s.cout, s.k,
-                                   kw if kw is not None else s.k, s.stride, pad if pad is not None else s.pad, stream_ptr()), "gic_conv2d " + s.name)
+        with self._traced(s.name):
+            _check(L.load().gic_conv2d(ptr(x), ptr(s.w), ptr(y), st, self._nrep[s.name], self.dtype, N, H, W, cin if cin is not None else s.cin, s.cout, s.k,
+                                       kw if kw is not None else s.k, s.stride, pad if pad is not None else s.pad, stream_ptr()), "gic_conv2d " + s.name)
 
     def _bn_relu_conv(self, prev: _ConvStep, y_prev, z_prev, s: _ConvStep, y, stats, training: bool, N, H, W, rows_prev) -> None:
         """z = relu(bn_prev(y_prev)); y = conv_s(z).  In bf16 training mode the normalisation rides in the convolution's A-operand
         path (gic_conv2d_bn_in: z_prev is never written); otherwise bn_act + convolution."""
         if training and self.fuse_in and s.fused_in is not False and self.dtype != L.F32:
             base = stats.data_ptr()
-            status = L.load().gic_conv2d_bn_in(ptr(y_prev), base + 4 * prev.stats_off, self._nrep[prev.name], ptr(prev.bn.weight.detach()),
-                                               ptr(prev.bn.bias.detach()), float(rows_prev), ptr(s.w), ptr(y), base + 4 * s.stats_off,
-                                               self._nrep[s.name], self.dtype, N, H, W, s.cin, s.cout, s.k, s.k, s.stride, s.pad,
-                                               stream_ptr())
+            with self._traced(s.name):
+                status = L.load().gic_conv2d_bn_in(ptr(y_prev), base + 4 * prev.stats_off, self._nrep[prev.name], ptr(prev.bn.weight.detach()),
+                                                   ptr(prev.bn.bias.detach()), float(rows_prev), ptr(s.w), ptr(y), base + 4 * s.stats_off,
+                                                   self._nrep[s.name], self.dtype, N, H, W, s.cin, s.cout, s.k, s.k, s.stride, s.pad,
+                                                   stream_ptr())
+            if status == L.ERR_UNSUPPORTED and self.conv_trace:
+                self.conv_trace.pop()
             if status == L.ERR_UNSUPPORTED:
                 s.fused_in = False
             else:
@@ -365,29 +397,35 @@ def head_bwd(dtype, saved, weight, gamma, d_out, grads=None):
     return dw, db, dg, dbt
 
 
-def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None):
-    """The dominant kernel of the step = the implicit-GEMM convolution kernel (every trunk convolution is a launch of
-    it).  Each distinct layer shape is replayed with its step shapes, BatchNorm-sum epilogue included, under HIP events
-    on the launch stream; `achieved` = algorithmic FLOPs of all 53 (R50) launches / their summed duration."""
+def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None, in_step=None):
+    """The dominant kernel of the step = the implicit-GEMM convolution kernel (every trunk convolution is a launch of it).
+
+    ``in_step`` = {layer name: [ms per launch, ...]} measured by bench.py with HIP events around every convolution launch on
+    its launch stream WHILE the real train step runs on the other streams (TrunkPlan.conv_trace): `achieved` / `frac` are
+    the algorithmic FLOPs of all launches / the summed in-step durations.  The isolated replay of each distinct layer shape
+    (hot caches, nothing else on the chip) is kept beside it under "isolated_replay"."""
     import sys
     plan = encoder.resnet._plan
     N, S = args.adv_train_batch_size, args.image_size
     stream = torch.cuda.current_stream()
     b = plan._buffers(N, S, encoder.linear.weight.device)
-    seen, plain_ms = {}, {}
+    seen = {}
+    per_layer_step_ms = {}
     for s, xi, yo, H, W, kw, macs, prev in plan.conv_shapes(N, S):
         key = (s.cin, s.cout, s.k, s.stride, H, bool(prev is not None and s.fused_in))
         if key not in seen:
             seen[key] = [event_time_ms(lambda: plan.replay(s, xi, yo, b["stats"], N, H, W, kw, prev), 5, stream), 0, macs,
-                         s.name + (" [bn+relu on load]" if key[5] else "")]
-            # the same layer as a plain convolution (its input normalised by a separate bn_act launch): for the side figure below
-            plain_ms[key] = event_time_ms(lambda: plan.replay(s, xi, yo, b["stats"], N, H, W, kw, None), 5, stream) if key[5] else seen[key][0]
+                         s.name + (" [bn+relu on load]" if key[5] else ""), 0.0]
         seen[key][1] += 1
-    total_ms = total_flops = bound_us = total_bytes = 0.0
+        if in_step and s.name in in_step:
+            v = in_step[s.name]
+            seen[key][4] += sum(v) / len(v)
+    total_ms = total_flops = bound_us = total_bytes = step_ms = 0.0
     launches = 0
     layers = []
-    for key, (ms, count, macs, name) in seen.items():
+    for key, (ms, count, macs, name, ms_step) in seen.items():
         total_ms += ms * count
+        step_ms += ms_step
         total_flops += 2.0 * macs * count
         launches += count
         tf = 2.0 * macs / (ms * 1e-3) / 1e12
@@ -397,22 +435,25 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None):
         floor_us = max(2.0 * macs / (peak_tflops * 1e12), nbytes / 8e12) * 1e6
         bound_us += floor_us * count
         total_bytes += nbytes * count
-        print(f"[conv] {name:30s} Cin={key[0]:5d} Cout={key[1]:5d} k={key[2]} s={key[3]} H={key[4]:4d} x{count}: {ms * 1e3:8.1f} us {tf:7.1f} TFLOP/s "
-              f"{nbytes / (ms * 1e-3) / 1e9:7.0f} GB/s  roofline floor {floor_us:6.1f} us", file=sys.stderr)
-    print(f"[conv] all {launches} launches: {total_ms * 1e3:.1f} us; per-layer max(MFMA, HBM) floor {bound_us:.1f} us", file=sys.stderr)
+        print(f"[conv] {name:30s} Cin={key[0]:5d} Cout={key[1]:5d} k={key[2]} s={key[3]} H={key[4]:4d} x{count}: isolated {ms * 1e3:7.1f} us {tf:7.1f} TFLOP/s "
+              f"{nbytes / (ms * 1e-3) / 1e9:6.0f} GB/s | in-step {ms_step / count * 1e3 if ms_step else float('nan'):7.1f} us | floor {floor_us:6.1f} us",
+              file=sys.stderr)
+    print(f"[conv] all {launches} launches: isolated {total_ms * 1e3:.1f} us, in-step {step_ms * 1e3:.1f} us; per-layer max(MFMA, HBM) floor {bound_us:.1f} us",
+          file=sys.stderr)
     layers.sort()
-    achieved = total_flops / (total_ms * 1e-3) / 1e12
-    plain_total = sum(plain_ms[k] * v[1] for k, v in seen.items())
+    iso = total_flops / (total_ms * 1e-3) / 1e12
+    use_ms = step_ms if step_ms > 0 else total_ms
+    achieved = total_flops / (use_ms * 1e-3) / 1e12
     fmt = lambda l: {"layer": l[1], "cin": l[2][0], "cout": l[2][1], "k": l[2][2], "stride": l[2][3], "tflops": round(l[0], 1), "us": round(l[3] * 1e3, 1)}
-    return {"kernel": "tile8_kernel<CONV, EPI_BNSTATS>: implicit-GEMM convolution, bf16 16x16x32 MFMA, 128x128|128x64 tile, 8 waves, LDS-DMA ring, "
-                      f"{launches} launches/step (every trunk convolution; the 16 conv3 launches also apply bn2 + ReLU to their A tiles in LDS)",
+    return {"kernel": "conv kernels of the ResNet trunk (tile8_kernel<CONV, EPI_BNSTATS> family): implicit-GEMM convolution, bf16 16x16x32 MFMA, 8 waves, "
+                      f"LDS-DMA ring, {launches} launches/step",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(achieved / peak_tflops, 4),
-            "traffic": pmc_traffic, "ms_per_launch": round(total_ms / launches, 5), "launches_per_step": launches,
-            "ms_per_step": round(total_ms, 4), "algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
+            "measured": ("HIP events around every convolution launch on its launch stream while the train step runs on the other streams"
+                         if step_ms > 0 else "isolated replay of each layer shape under HIP events"),
+            "traffic": pmc_traffic, "ms_per_launch": round(use_ms / launches, 5), "launches_per_step": launches,
+            "ms_per_step": round(use_ms, 4), "algorithmic_gflop_per_step": round(total_flops / 1e9, 1),
             "algorithmic_bytes_per_launch": int(total_bytes / launches),
             "floor_ms_per_step": round(bound_us / 1e3, 4),      # sum over layers of max(flops / MFMA peak, bytes / 8 TB/s)
-            "frac_of_floor": round(bound_us / 1e3 / total_ms, 4),
-            # the same 53 layers with every input normalised by its own bn_act launch instead (what the fused launches replace)
-            "plain_conv_variant": {"ms_per_step": round(plain_total, 4), "achieved": round(total_flops / (plain_total * 1e-3) / 1e12, 2),
-                                   "frac": round(total_flops / (plain_total * 1e-3) / 1e12 / peak_tflops, 4)},
+            "frac_of_floor": round(bound_us / 1e3 / use_ms, 4),
+            "isolated_replay": {"ms_per_step": round(total_ms, 4), "achieved": round(iso, 2), "frac": round(iso / peak_tflops, 4)},
             "slowest_layer": fmt(layers[0]), "fastest_layer": fmt(layers[-1])}

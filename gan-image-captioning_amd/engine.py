@@ -337,7 +337,8 @@ class DiscEngine:
     OUT = 100
     OUT_PAD = 104
 
-    def __init__(self, vocab: int, embed_dim: int, num_rep: int, filter_sizes: Sequence[int], num_filters: Sequence[int], dtype: int):
+    def __init__(self, vocab: int, embed_dim: int, num_rep: int, filter_sizes: Sequence[int], num_filters: Sequence[int], dtype: int,
+                 dropout: float = 0.2):
         if len(filter_sizes) != len(num_filters) or not 1 <= len(filter_sizes) <= L.MAX_CONVS:
             raise ValueError("disc_filter_sizes / disc_num_filters must have equal length in 1..%d" % L.MAX_CONVS)
         if embed_dim % num_rep:
@@ -349,6 +350,9 @@ class DiscEngine:
         self.s = embed_dim // num_rep
         self.dt = dtype
         self.act = TORCH_DTYPE[dtype]
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError("dropout probability has to be in [0, 1), got %r" % (dropout,))
+        self.drop_p = float(dropout)
         self._shadow = None
         self._shadow_key = None
 
@@ -361,7 +365,7 @@ class DiscEngine:
         d.B, d.L, d.V, d.De, d.R, d.nconv = B, Lc, self.V, self.De, self.R, len(self.fs)
         d.fsize = _arr(C.c_int32, L.MAX_CONVS, self.fs)
         d.nfilt = _arr(C.c_int32, L.MAX_CONVS, self.nf)
-        d.F, d.Fp, d.dtype = self.F, self.Fp, self.dt
+        d.F, d.Fp, d.dtype, d.drop_p = self.F, self.Fp, self.dt, self.drop_p
         return d
 
     def _pstruct(self, params, cls=L.DiscParams):

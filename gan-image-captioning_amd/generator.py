@@ -32,9 +32,12 @@ class _SeedStream:
     def __init__(self):
         self._n = 0
 
+    rank = 0        # data-parallel rank (set by GANInstructor): replicas draw DIFFERENT Gumbel noise / dropout masks
+
     def next(self) -> int:
         self._n += 1
-        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._n * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._n * 0xD1B54A32D192ED03
+                + self.rank * 0xA0761D6478BD642F) & (2 ** 64 - 1)
 
 
 SEEDS = _SeedStream()
@@ -227,6 +230,11 @@ class Encoder(nn.Module):
         s = self._s_pre
         with torch.cuda.stream(s):
             s.wait_event(after)                 # `images` is ready
+            busy, self._busy = getattr(self, "_busy", None), None
+            if busy is not None:
+                # a synchronous pass on another stream (cold step, mispredicted look-ahead) is still using the plan's
+                # shared buffers (packed image, statistics arena, activations): this pass starts behind it
+                s.wait_event(busy)
             if mark is not None:
                 mark("trunk prefetch start [s_pre]", s)
             feats = self.trunk_features(images, training).clone()
@@ -244,7 +252,14 @@ class Encoder(nn.Module):
             if pre[0] is images and pre[1] == bool(training):
                 pre[2].record_stream(stream)
                 return pre[2]
-        return self.trunk_features(images, training)
+        # synchronous pass: hand out a private copy (the plan's own output buffer is overwritten by the next pass, which may
+        # run on the look-ahead stream) and remember where this pass ends for prefetch_trunk
+        busy = getattr(self, "_busy", None)
+        if busy is not None:
+            stream.wait_event(busy)             # an earlier synchronous pass on some other stream
+        feats = self.trunk_features(images, training).clone()
+        self._busy = stream.record_event()
+        return feats
 
     # ---- direct (no autograd) forms used by the fused step driver
     def trunk_features(self, images, training: bool):

@@ -110,10 +110,3 @@ class GradReducer:
         for ev in self._pending:
             torch.cuda.current_stream().wait_event(ev)
         self._pending.clear()
-
-
-def allreduce_stats(t: torch.Tensor, info: DistInfo) -> torch.Tensor:
-    """Sum-all-reduce of small per-channel statistics (BatchNorm sync option)."""
-    if info.world_size > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t

@@ -77,6 +77,8 @@ class GANInstructor:
     def __init__(self, args, train_dataset, dev_dataset):
         self.args = args
         self.dist = parallel.DistInfo.from_env()
+        from .generator import SEEDS
+        SEEDS.rank = self.dist.rank            # replicas share weights and the torch seed, not the device noise streams
         self.gen = Generator(args).to(args.device)                        # training.py:19
         self.disc = Discriminator(args).to(args.device)                   # training.py:20
         self.cgan = (args.conditional_gan == 1)
@@ -103,14 +105,17 @@ class GANInstructor:
 
         self.train_dataset, self.dev_dataset = train_dataset, dev_dataset
         nw = int(getattr(args, "num_workers", 4))
-        mk = lambda ds, bs, shuffle: None if ds is None else DataLoader(   # noqa: E731  (training.py:28-32)
-            ds, shuffle=shuffle, batch_size=bs, collate_fn=collate_fn, num_workers=nw,
-            sampler=parallel.shard_sampler(ds, self.dist, shuffle) if self.dist.world_size > 1 else None)
         dp = self.dist.world_size > 1
-        self.pre_train_loader = mk(train_dataset, args.pre_train_batch_size, not dp)
+        # training.py:28-32 (shuffle=True for the two train loaders).  Under data parallelism the shuffling moves into the
+        # DistributedSampler (the DataLoader itself must not shuffle when it is given a sampler); set_epoch() in the loops.
+        mk = lambda ds, bs, shuffle: None if ds is None else DataLoader(   # noqa: E731
+            ds, shuffle=shuffle and not dp, batch_size=bs, collate_fn=collate_fn, num_workers=nw,
+            sampler=parallel.shard_sampler(ds, self.dist, shuffle) if dp else None)
+        self.pre_train_loader = mk(train_dataset, args.pre_train_batch_size, True)
         self.pre_eval_loader = mk(dev_dataset, args.pre_eval_batch_size, False)
-        self.adv_train_loader = mk(train_dataset, args.adv_train_batch_size, not dp)
+        self.adv_train_loader = mk(train_dataset, args.adv_train_batch_size, True)
         self.adv_eval_loader = mk(dev_dataset, args.adv_eval_batch_size, False)
+        self._sampler_epoch = 0
 
         self.model_dir = getattr(args, "model_dir", None)
         self.writer = _ScalarWriter(getattr(args, "save_dir", None) if rank0 and getattr(args, "log_file", None) else None)
@@ -125,6 +130,12 @@ class GANInstructor:
             return self.gen.encoder(images, next_images=next_images)       # training.py:66,145
         ones = torch.ones(batch, dtype=torch.long, device=self.args.device)
         return self.gen.decoder.embed(ones)                                # training.py:68,147
+
+    def _reshuffle(self, loader, what) -> None:
+        """Data parallel: a new permutation per pass over the training set (DistributedSampler.set_epoch), same on every rank."""
+        if what == "train" and self.dist.world_size > 1 and hasattr(getattr(loader, "sampler", None), "set_epoch"):
+            loader.sampler.set_epoch(self._sampler_epoch)
+            self._sampler_epoch += 1
 
     def update_temperature(self, i, N):
         self.gen.decoder.temperature = get_fixed_temperature(self.args.temperature, i, N, self.args.temp_adpt)
@@ -152,12 +163,16 @@ class GANInstructor:
         gen_loss = []
         loader = self.pre_train_loader if what == "train" else self.pre_eval_loader
         total = len(self.train_dataset) if what == "train" else len(self.dev_dataset)
+        self._reshuffle(loader, what)
         with (torch.enable_grad() if what == "train" else torch.no_grad()), \
                 tqdm(total=total, disable=self.dist.rank != 0) as progress:
             for (images, captions, lengths, max_caption_len), nxt in _lookahead(loader, self.args.device):
                 loss = self.pretrain_step(images, captions, max_caption_len, train=(what == "train"),
                                           next_images=nxt[0] if nxt is not None and nxt[0].shape == images.shape else None)
                 val = loss.item()
+                if val != val:      # gic_xent poisons the loss when a target is outside [0, V) (nn.CrossEntropyLoss would raise)
+                    raise ValueError("pre-train loss is NaN: a caption token is outside [0, vocab_size=%d) or the logits overflowed"
+                                     % self.args.vocab_size)
                 gen_loss.append(val)
                 self.writer.add_scalar("GenPreTraining_train_loss" if what == "train" else "GenPreTraining_val_loss",
                                        val, self.pretrain_steps)
@@ -226,6 +241,7 @@ class GANInstructor:
     def adv_loop(self, what):
         loader = self.adv_train_loader if what == "train" else self.adv_eval_loader
         total = len(self.train_dataset) if what == "train" else len(self.dev_dataset)
+        self._reshuffle(loader, what)
         float_epoch = 0.0
         gen_loss, disc_loss = [], []
         with tqdm(total=total, disable=self.dist.rank != 0) as progress:

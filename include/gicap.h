@@ -176,6 +176,7 @@ typedef struct gic_disc_dims {
   int32_t F;                             /* sum(nfilt) */
   int32_t Fp;                            /* leading dim of the [B*R, F] activations (>= F, multiple of 8) */
   int32_t dtype;
+  float drop_p;                          /* nn.Dropout p before feature2out (discriminator.py:10,30; default 0.2), 0 <= p < 1 */
 } gic_disc_dims;
 
 typedef struct gic_disc_params {
@@ -227,7 +228,7 @@ int gic_disc_prepare(const gic_disc_dims* dims, const gic_disc_params* params, c
 
 /* Exactly one of inp_soft (act [B*L, V], row stride ld_inp, rows in (b,l) order) and inp_ids (int64 [B,L];
  * the one-hot of training.py:158 evaluated as a gather) is non-NULL.
- * train != 0: dropout(0.2) with keep_mask (uint8 0/1 [B*R,F], row stride F) or, if NULL, Philox(seed).
+ * train != 0: dropout(dims->drop_p) with keep_mask (uint8 0/1 [B*R,F], row stride F) or, if NULL, Philox(seed).
  * logits: f32 [B*R]. */
 int gic_disc_fwd(const gic_disc_dims* dims, const gic_disc_params* params, const gic_disc_shadow* shadow,
                  const gic_disc_state* state, const void* inp_soft, int64_t ld_inp, const int64_t* inp_ids,

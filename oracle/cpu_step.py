@@ -55,7 +55,8 @@ def num_lstm_layers(gp: Params, prefix: str = "decoder.") -> int:
 
 def decoder_sample(gp: Params, features: Tensor, max_caption_len: int,
                    temperature: float, us: Optional[Sequence[Tensor]] = None,
-                   pretrain: bool = False, prefix: str = "decoder."
+                   pretrain: bool = False, prefix: str = "decoder.",
+                   force_ids: Optional[Tensor] = None, states: Optional[Tuple[Tensor, Tensor]] = None
                    ) -> Tuple[Tensor, Tensor]:
     """Decoder.sample (src/generator.py:55-81).
 
@@ -64,12 +65,20 @@ def decoder_sample(gp: Params, features: Tensor, max_caption_len: int,
     (outputs [B,L,V], ids int64 [B,L]).  In adversarial mode outputs are
     softmax((o+g)*T); in pretrain mode raw logits (src/generator.py:63-66).
     The next input is embed(argmax) with the index detached (:73-76).
+
+    ``force_ids`` [B,L] (test aid, no reference counterpart): the trajectory to follow instead of the argmax -- the index is
+    detached in the reference (:75), so the outputs' gradient on a GIVEN trajectory is the same function; used to compare
+    gradients with a bf16 run whose argmax differs at a near-tie.  ``states`` = (h0, c0), each [num_layers, B, H] (:55,61).
     """
     nl = num_lstm_layers(gp, prefix)
     bsz = features.shape[0]
     hid = gp[f"{prefix}lstm.weight_hh_l0"].shape[1]
-    h = [features.new_zeros(bsz, hid) for _ in range(nl)]
-    c = [features.new_zeros(bsz, hid) for _ in range(nl)]
+    if states is None:
+        h = [features.new_zeros(bsz, hid) for _ in range(nl)]
+        c = [features.new_zeros(bsz, hid) for _ in range(nl)]
+    else:
+        h = [states[0][l] for l in range(nl)]
+        c = [states[1][l] for l in range(nl)]
     x = features
     outs: List[Tensor] = []
     ids: List[Tensor] = []
@@ -89,6 +98,8 @@ def decoder_sample(gp: Params, features: Tensor, max_caption_len: int,
             pred = torch.softmax((o + g) * temperature, dim=-1)
             outs.append(pred)
         idx = pred.max(1)[1]                       # first maximal index
+        if force_ids is not None:
+            idx = force_ids[:, t]
         ids.append(idx)
         x = gp[f"{prefix}embed.weight"][idx.detach()]
     return torch.stack(outs, 1), torch.stack(ids, 1)
@@ -170,11 +181,12 @@ def disc_num_convs(dp: Params) -> int:
 
 
 def disc_forward(dp: Params, inp: Tensor, keep_mask: Optional[Tensor] = None,
-                 num_rep: int = 64, return_stages: bool = False):
+                 num_rep: int = 64, return_stages: bool = False, dropout_p: float = DROPOUT_P):
     """inp [B,L,V] float -> logits [B*num_rep].
 
     keep_mask: 0/1 tensor [B*num_rep, F] (dropout keep mask, train mode,
-    src/discriminator.py:30,58) or None for eval mode.
+    src/discriminator.py:30,58) or None for eval mode.  dropout_p: the constructor's
+    ``dropout`` argument (src/discriminator.py:10; nn.Dropout scales kept values by 1/(1-p)).
     """
     bsz, seqlen, _ = inp.shape
     emb = inp @ dp["embeddings.weight"].t()                        # :40  [B,L,De]
@@ -196,7 +208,7 @@ def disc_forward(dp: Params, inp: Tensor, keep_mask: Optional[Tensor] = None,
     hw = pooled @ dp["highway.weight"].t() + dp["highway.bias"]    # :53
     sig = torch.sigmoid(hw)
     hwout = sig * torch.relu(hw) + (1.0 - sig) * pooled            # :55
-    dropped = hwout if keep_mask is None else hwout * (keep_mask / (1.0 - DROPOUT_P))
+    dropped = hwout if keep_mask is None else hwout * (keep_mask / (1.0 - dropout_p))
     feat = dropped @ dp["feature2out.weight"].t() + dp["feature2out.bias"]   # :58
     logits = (feat @ dp["out2logits.weight"].t() + dp["out2logits.bias"]).squeeze(1)  # :60
     if return_stages:
@@ -310,7 +322,8 @@ def adv_step(gp: Params, dp: Params, captions: Tensor, us: Sequence[Tensor],
              loss_type: str = "standard", clip_norm: float = 5.0,
              gen_opt: Optional[AdamState] = None, disc_opt: Optional[AdamState] = None,
              trunk_feat: Optional[Tensor] = None, num_rep: int = 64,
-             bn_running: Optional[Dict[str, Tensor]] = None, train: bool = True) -> Dict[str, object]:
+             bn_running: Optional[Dict[str, Tensor]] = None, train: bool = True,
+             force_ids: Optional[Tensor] = None, dropout_p: float = DROPOUT_P) -> Dict[str, object]:
     """One adversarial G+D step with the fixed order: both backward passes on
     pre-update weights, then both optimizer steps (the literal order of
     src/training.py:168-169 cannot run on torch >= 1.5).
@@ -331,12 +344,12 @@ def adv_step(gp: Params, dp: Params, captions: Tensor, us: Sequence[Tensor],
         feats = encoder_head(g_leaf, trunk_feat, training=train, running=bn_running)
     else:
         feats = start_features(g_leaf, bsz)
-    gen, ids = decoder_sample(g_leaf, feats, seqlen, temperature, us)
+    gen, ids = decoder_sample(g_leaf, feats, seqlen, temperature, us, force_ids=force_ids)
     real = torch.nn.functional.one_hot(captions, vocab).float()       # training.py:158
     m = masks if masks is not None else (None, None, None)
-    d_real, st_real = disc_forward(d_leaf, real, m[0], num_rep, return_stages=True)
-    d_fake, st_fake = disc_forward(d_leaf, gen.detach(), m[1], num_rep, return_stages=True)
-    g_out, st_gen = disc_forward(d_leaf, gen, m[2], num_rep, return_stages=True)
+    d_real, st_real = disc_forward(d_leaf, real, m[0], num_rep, return_stages=True, dropout_p=dropout_p)
+    d_fake, st_fake = disc_forward(d_leaf, gen.detach(), m[1], num_rep, return_stages=True, dropout_p=dropout_p)
+    g_out, st_gen = disc_forward(d_leaf, gen, m[2], num_rep, return_stages=True, dropout_p=dropout_p)
     g_loss, d_loss = get_losses(d_real, d_fake, g_out, loss_type)
     out: Dict[str, object] = {
         "probs": gen.detach(), "ids": ids, "d_real": d_real.detach(), "d_fake": d_fake.detach(),

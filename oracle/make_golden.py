@@ -277,6 +277,85 @@ def run_forward_case(case: dict) -> dict:
     return out
 
 
+def run_api_case(case: dict) -> dict:
+    """Module-API corners the trainer never exercises but the signatures offer:
+    ``Decoder.sample(features, states=(h0, c0))`` with gradients into the states (generator.py:55,61);
+    ``Discriminator(args, dropout=p)`` with p != 0.2 (discriminator.py:10,30);
+    ``Decoder.forward`` differentiated (teacher forcing with packed sequences, generator.py:39-53)."""
+    torch.manual_seed(1008)
+    B, L, V, E, H, NL = (case[k] for k in ("B", "L", "V", "E", "H", "NL"))
+    R, De, F = case["R"], case["De"], sum(case["nf"])
+    pg = torch.Generator().manual_seed(case["param_seed"])
+    gp = O.make_gen_params(V, E, H, NL, pg)
+    dp = O.make_disc_params(V, pg, embed_dim=De, num_rep=R, filter_sizes=case["fs"], num_filters=case["nf"])
+    gp = {k: v * case["g_scale"] for k, v in gp.items()}
+    caps = O.make_captions(B, L, V, pg)
+    feats = torch.randn(B, E, generator=pg) * 0.3
+    h0 = torch.randn(NL, B, H, generator=pg) * 0.5
+    c0 = torch.randn(NL, B, H, generator=pg) * 0.5
+    rg, rd, _ = ref_stub.load()
+    args = ref_stub.make_args(V, E, H, NL, temperature=case["T"], disc_embed_dim=De, disc_num_rep=R,
+                              filter_sizes=case["fs"], num_filters=case["nf"])
+    dec = rg.Decoder(args)
+    dec.load_state_dict({k[len("decoder."):]: v.clone() for k, v in gp.items()})
+    out = {"caps": _np(caps), "feats": _np(feats), "h0": _np(h0), "c0": _np(c0)}
+    for k, v in {**gp, **dp}.items():
+        out[f"p0/{k}"] = _np(v)
+
+    # ---- sample(states=...)
+    f_l, h_l, c_l = feats.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    torch.manual_seed(case["noise_seed"])
+    probs, ids = dec.sample(f_l, states=(h_l, c_l), max_caption_len=L)
+    torch.manual_seed(case["noise_seed"])
+    us = [torch.zeros(B, V).uniform_(0, 1) for _ in range(L)]
+    d_out = torch.randn(probs.shape, generator=pg)
+    dec.zero_grad()
+    (probs * d_out).sum().backward()
+    out.update({"st/u": _np(torch.stack(us)), "st/probs": _np(probs), "st/ids": _np(ids), "st/d_out": _np(d_out),
+                "st/d_feats": _np(f_l.grad), "st/d_h0": _np(h_l.grad), "st/d_c0": _np(c_l.grad)})
+    for k, p_ in dec.named_parameters():
+        out["st/grad/decoder." + k] = _np(p_.grad)
+    mine_p, mine_i = O.decoder_sample(gp, feats, L, case["T"], us, states=(h0, c0))
+    assert torch.equal(mine_i, ids) and torch.allclose(mine_p, probs, rtol=1e-4, atol=1e-7)
+
+    # ---- Decoder.forward differentiated (both modes share the LSTM; pretrain=True keeps the check free of noise)
+    lengths = case["lengths"]
+    f_l = feats.clone().requires_grad_(True)
+    dec.zero_grad()
+    logits, (h_n, c_n) = dec(f_l, caps, torch.tensor(lengths), pretrain=True)
+    d_log = torch.randn(logits.shape, generator=pg)
+    (logits * d_log).sum().backward()
+    out.update({"tf/lengths": np.array(lengths, dtype=np.int32), "tf/logits": _np(logits), "tf/d_logits": _np(d_log),
+                "tf/d_feats": _np(f_l.grad)})
+    for k, p_ in dec.named_parameters():
+        out["tf/grad/decoder." + k] = _np(p_.grad)
+
+    # ---- Discriminator(dropout=p)
+    disc = rd.Discriminator(args, dropout=case["dropout"])
+    disc.load_state_dict({k: v.clone() for k, v in dp.items()})
+    disc.train()
+    captured = []
+    hook = disc.dropout.register_forward_hook(lambda m_, i, o: captured.append((i[0].detach().clone(), o.detach().clone())))
+    soft = torch.softmax(torch.randn(B, L, V, generator=pg) * 2, -1).requires_grad_(True)
+    torch.manual_seed(case["noise_seed"] + 1)
+    logit = disc(soft)
+    torch.manual_seed(case["noise_seed"] + 1)
+    mask = torch.empty(B * R, F).bernoulli_(1 - case["dropout"])
+    assert torch.equal(captured[0][0] * (mask / (1 - case["dropout"])), captured[0][1]), "dropout replay mismatch"
+    hook.remove()
+    d_logit = torch.randn(logit.shape, generator=pg)
+    disc.zero_grad()
+    (logit * d_logit).sum().backward()
+    out.update({"dr/inp": _np(soft), "dr/mask": np.packbits(_np(mask).astype(np.uint8), axis=-1), "dr/logits": _np(logit),
+                "dr/d_logits": _np(d_logit), "dr/d_inp": _np(soft.grad)})
+    for k, p_ in disc.named_parameters():
+        out["dr/grad/" + k] = _np(p_.grad)
+    mine = O.disc_forward(dp, soft.detach(), mask, R, dropout_p=case["dropout"])
+    assert torch.allclose(mine, logit, rtol=1e-4, atol=1e-6)
+    out["meta"] = np.array(json.dumps(case))
+    return out
+
+
 def run_scalar_cases() -> dict:
     """get_losses for every functional loss type + the temperature schedules."""
     _, _, ru = ref_stub.load()
@@ -313,6 +392,8 @@ CASES = [
     dict(BASE, name="cfg1", B=8, L=10, V=64, E=32, H=512, NL=1, nf=[300, 300, 300], steps=2, full=False),
 ]
 FORWARD_TF = dict(name="forward_tf_tiny", B=4, L=6, V=50, E=8, H=16, NL=2, T=1.3, lengths=[7, 5, 3, 6], param_seed=2025)
+API = dict(name="api_tiny", B=4, L=6, V=50, E=8, H=16, NL=2, R=64, De=64, fs=[3, 4, 5], nf=[20, 30, 10], T=1.3, g_scale=8.0,
+           lengths=[7, 5, 3, 6], dropout=0.5, param_seed=2026, noise_seed=17)
 PRETRAIN = dict(name="pretrain_tiny", B=4, L=6, V=50, E=8, H=16, NL=2, steps=2, clip=5.0, pretrain_lr=1e-2, param_seed=2024)
 
 
@@ -328,6 +409,8 @@ def main() -> int:
     print("pretrain_tiny: loss", res["s0/loss"])
     np.savez_compressed(os.path.join(GOLDEN_DIR, "forward_tf_tiny.npz"), **run_forward_case(FORWARD_TF))
     print("forward_tf_tiny written")
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "api_tiny.npz"), **run_api_case(API))
+    print("api_tiny written")
     np.savez_compressed(os.path.join(GOLDEN_DIR, "scalars.npz"), **run_scalar_cases())
     return 0
 

@@ -43,8 +43,12 @@ def run(out_path):
         out = inst.fused(None, caps_r, L, True, us_r, masks_r)
         losses.append(out["losses"].clone())
     torch.cuda.synchronize()
-    torch.save({"gen": inst.gen_arena.flat.cpu(), "disc": inst.disc_arena.flat.cpu(), "losses": torch.stack(losses).cpu(),
-                "d_norm": float(inst.disc_opt.grad_norm), "world": info.world_size}, out_path % info.rank)
+    result = {"gen": inst.gen_arena.flat.cpu(), "disc": inst.disc_arena.flat.cpu(), "losses": torch.stack(losses).cpu(),
+              "d_norm": float(inst.disc_opt.grad_norm), "world": info.world_size}
+    # one more step with DEVICE-drawn noise on identical inputs: the replicas must not draw the same Gumbel noise (seed mixes the rank)
+    same = caps[:B // info.world_size].to(dev)
+    result["free_ids"] = inst.fused(None, same, L, True, None, None, opt_step=False)["ids"].cpu()
+    torch.save(result, out_path % info.rank)
     if info.world_size > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

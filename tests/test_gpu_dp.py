@@ -34,3 +34,28 @@ def test_two_ranks_reproduce_the_single_process_step(tmp_path):
     assert r0["d_norm"] == pytest.approx(one["d_norm"], rel=1e-4)      # norm of the AVERAGED gradient, not of a shard's
     torch.testing.assert_close(r0["disc"], one["disc"], rtol=1e-4, atol=2e-6)
     torch.testing.assert_close(r0["gen"], one["gen"], rtol=1e-4, atol=2e-6)
+    # device-drawn noise differs between the replicas (same weights, same inputs, same torch seed)
+    assert not torch.equal(r0["free_ids"], r1["free_ids"])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_ranks_over_rccl_reproduce_the_single_process_step(tmp_path):
+    """The production collective path itself (GradReducer's device branch: RCCL ReduceOp.AVG on the side stream, early bucket of
+    G's arena, D's Adam gated on its own collective) on two GPUs; runs wherever >= 2 devices are visible."""
+    worker = os.path.join(ROOT, "tests", "dp_gpu_worker.py")
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GIC_DIST_BACKEND"):
+        env.pop(k, None)
+    single = str(tmp_path / "single_%d.pt")
+    r = subprocess.run([sys.executable, worker, single], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    multi = str(tmp_path / "multi_%d.pt")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29534", worker, multi], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    one = torch.load(single % 0)
+    r0, r1 = torch.load(multi % 0), torch.load(multi % 1)
+    assert torch.equal(r0["gen"], r1["gen"]) and torch.equal(r0["disc"], r1["disc"])
+    torch.testing.assert_close((r0["losses"] + r1["losses"]) / 2, one["losses"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(r0["disc"], one["disc"], rtol=1e-4, atol=2e-6)
+    torch.testing.assert_close(r0["gen"], one["gen"], rtol=1e-4, atol=2e-6)

@@ -485,11 +485,14 @@ def test_bf16_decoder_and_disc_close_to_f32_oracle(E, dev):
     match = float((ids.cpu() == ids_ref).float().mean())
     print(f"bf16 id match-rate vs fp32 oracle: {match:.3f}")
     assert match > 0.9
-    if match == 1.0:
-        gerrs = {n: rel_l2(gt, gleaf[n].grad) for n, gt in zip(gnames, ggr[:-1])}
-        gerrs["probs"] = rel_l2(out.float(), probs)
-        print("bf16 decoder rel-L2 errors:", {k: f"{v:.1e}" for k, v in gerrs.items()})
-        assert max(gerrs.values()) < 3e-2, gerrs
+    if match < 1.0:      # a bf16 near-tie flipped an argmax: the oracle follows the GPU's trajectory (the index carries no gradient)
+        gleaf = {k: gp[k].clone().requires_grad_(True) for k in gnames}
+        probs, _ = O.decoder_sample(gleaf, feats, Lc, T, us, force_ids=ids.cpu())
+        (probs * d_out).sum().backward()
+    gerrs = {n: rel_l2(gt, gleaf[n].grad) for n, gt in zip(gnames, ggr[:-1])}
+    gerrs["probs"] = rel_l2(out.float(), probs)
+    print("bf16 decoder rel-L2 errors:", {k: f"{v:.1e}" for k, v in gerrs.items()})
+    assert max(gerrs.values()) < 3e-2, gerrs
     # discriminator on the oracle's probabilities
     dleaf = {k: dp[k].clone().requires_grad_(True) for k in dnames}
     p_leaf = probs.detach().clone().requires_grad_(True)

@@ -231,8 +231,116 @@ def test_bf16_step_at_bench_scale_close_to_oracle():
     for n in ("highway.weight", "feature2out.weight", "out2logits.weight", "embeddings.weight"):
         err = rel_l2(dgot[n], ref["d_grads_raw"][n])
         assert err < 8e-2, f"{n}: rel L2 {err}"
-    if match == 1.0:        # G's gradient flows through the sampled trajectory: comparable only if it is the same one
-        ggot = {n: p.grad for n, p in zip(dec_param_names(1), inst.gen.decoder.param_list())}
-        for n in ("decoder.linear.weight", "decoder.lstm.weight_hh_l0"):
-            err = rel_l2(ggot[n], ref["g_grads_raw"][n])
-            assert err < 8e-2, f"{n}: rel L2 {err}"
+    # G's gradient flows through the sampled trajectory.  The index is detached (generator.py:75), so on a GIVEN trajectory the
+    # gradient is the same function of the weights: where a bf16 near-tie flipped an argmax, the oracle is re-run on the GPU's own
+    # trajectory (force_ids) and the comparison is made unconditionally.
+    if match < 1.0:
+        ref = O.adv_step(dict(gp), dict(dp), caps, us, masks, T, "standard", 5.0, None, None, force_ids=out["ids"].cpu())
+    ggot = {n: p.grad for n, p in zip(dec_param_names(1), inst.gen.decoder.param_list())}
+    for n in ("decoder.linear.weight", "decoder.lstm.weight_hh_l0", "decoder.lstm.weight_ih_l0", "decoder.embed.weight"):
+        err = rel_l2(ggot[n], ref["g_grads_raw"][n])
+        assert err < 8e-2, f"{n}: rel L2 {err}"
+
+
+def test_cfg2_composed_step_bf16_vs_oracle():
+    """BASELINE configs[1] itself, composed: --conditional-gan 1, ResNet-50-shaped trunk at 224x224, B=64, L=20, V=10000, E=H=512,
+    bf16 compute, ONE step through FusedAdvStep with explicit Gumbel uniforms / dropout masks, against the fp32 CPU oracle
+    (oracle.cpu_step.adv_step on oracle.cpu_encoder.trunk_forward's features; body of reference src/training.py:144-169).
+    Tolerances per tensor are written below; the per-stage trunk error (the budget behind the 5e-2 of the pooled features) is
+    asserted stage by stage and recorded in gpurun_out/cfg2_parity.json."""
+    import json
+    import os
+    from oracle import cpu_encoder as OE
+    from oracle import cpu_step as O
+    from tests.gpu_util import dec_param_names, disc_param_names, rel_l2
+    from gan_image_captioning_amd.args import default_args
+    from gan_image_captioning_amd.training import GANInstructor
+    B, L, V, E, H = 64, 20, 10000, 512, 512
+    g = torch.Generator().manual_seed(4242)
+    gp = O.make_gen_params(V, E, H, 1, g, trunk_feat_dim=OE.out_features("resnet50"))
+    dp = O.make_disc_params(V, g)
+    tp = OE.make_trunk_params("resnet50", g)
+    caps = O.make_captions(B, L, V, g)
+    images = torch.randn(B, 3, 224, 224, generator=g)
+    us, masks = O.make_noise(B, L, V, 900, 64, g)
+    T = 1.7
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    taps = {}
+    with torch.no_grad():
+        feat = OE.trunk_forward(tp, images, "resnet50", taps=taps)
+    ref = O.adv_step(dict(gp), dict(dp), caps, us, masks, T, "standard", 5.0, None, None, trunk_feat=feat)
+
+    args = default_args(vocab_size=V, gen_embed_dim=E, gen_hidden_dim=H, conditional_gan=1, encoder_arch="resnet50", compute_dtype="bf16",
+                        step_impl="fused", adv_train_batch_size=B, image_size=224, device="cuda", log_file=None, model_dir=None, save_dir=None)
+    inst = GANInstructor(args, None, None)
+    dev = args.device
+    with torch.no_grad():
+        for n, p in zip(dec_param_names(1), inst.gen.decoder.param_list()):
+            p.copy_(gp[n])
+        for n, p in zip(disc_param_names(3), inst.disc.param_list()):
+            p.copy_(dp[n])
+        inst.gen.encoder.resnet.load_state_dict({k[len("encoder.resnet."):]: v for k, v in tp.items()}, strict=False)
+        enc = inst.gen.encoder
+        for n in ("linear.weight", "linear.bias", "bn.weight", "bn.bias"):
+            mod, attr = n.split(".")
+            getattr(getattr(enc, mod), attr).copy_(gp["encoder." + n])
+    inst.gen.train(); inst.disc.train()
+    inst.gen.decoder.temperature = T
+    out = inst.fused(images.to(dev), caps.to(dev), L, True, torch.stack(us).to(dev), [k.to(dev) for k in masks], opt_step=False)
+    torch.cuda.synchronize()
+    report = {}
+
+    # ---- trunk, stage by stage (the B=64 plan: the ring variants the benchmark runs).  Budget: each stage adds bf16 rounding of
+    # 3-4 BatchNorm-normalised convolution outputs per block; the pooled feature averages 49 positions.
+    plan = enc.resnet._plan
+    pb = plan._bufs[(B, 224)]
+    stage_last = []
+    i = -1
+    for stage in enc.resnet.stages():
+        i += len(stage)
+        stage_last.append(i)
+    budget = {"stem": 1.5e-2, "stage0": 3e-2, "stage1": 4e-2, "stage2": 5e-2, "stage3": 6e-2, "pooled": 5e-2}
+    got_taps = {"stem": pb["x0"]}
+    for si, bi in enumerate(stage_last):
+        got_taps[f"stage{si}"] = pb["blocks"][bi]["out"]
+    for k, t in got_taps.items():
+        report["trunk_rel_l2/" + k] = rel_l2(t.float().permute(0, 3, 1, 2), taps[k])
+    # the plan's own feature buffer still holds this step's pooled output (no later pass ran)
+    report["trunk_rel_l2/pooled"] = rel_l2(pb["feat"].float(), feat)
+    for k, lim in budget.items():
+        assert report["trunk_rel_l2/" + k] < lim, f"trunk {k}: rel L2 {report['trunk_rel_l2/' + k]:.3e} over its budget {lim}"
+
+    # ---- roll-out: token ids (bf16 near-ties may flip an argmax; everything downstream then follows the GPU's trajectory)
+    ids = out["ids"].cpu()
+    match = float((ids == ref["ids"]).float().mean())
+    report["id_match_rate"] = match
+    assert match >= 0.9
+    if match < 1.0:
+        ref = O.adv_step(dict(gp), dict(dp), caps, us, masks, T, "standard", 5.0, None, None, trunk_feat=feat, force_ids=ids)
+    report["probs_rel_l2"] = rel_l2(out["probs"].float(), ref["probs"])
+    assert report["probs_rel_l2"] < 5e-2
+    # ---- losses: rel 2e-2 (d_loss) / 3e-2 (g_loss), SURVEY §8(c)
+    gl, dl = (float(v) for v in out["losses"])
+    report["g_loss"], report["g_loss_ref"], report["d_loss"], report["d_loss_ref"] = gl, ref["g_loss"], dl, ref["d_loss"]
+    assert dl == pytest.approx(ref["d_loss"], rel=2e-2)
+    assert gl == pytest.approx(ref["g_loss"], rel=3e-2)
+    # ---- gradients: relative L2 per tensor, D 8e-2, G 8e-2 (encoder head 1e-1: it sees the trunk's 5e-2 feature error)
+    dgot = {n: p.grad for n, p in zip(disc_param_names(3), inst.disc.param_list())}
+    ggot = {n: p.grad for n, p in zip(dec_param_names(1), inst.gen.decoder.param_list())}
+    ggot.update({"encoder.linear.weight": enc.linear.weight.grad, "encoder.linear.bias": enc.linear.bias.grad,
+                 "encoder.bn.weight": enc.bn.weight.grad, "encoder.bn.bias": enc.bn.bias.grad})
+    for n in ("highway.weight", "feature2out.weight", "out2logits.weight", "embeddings.weight", "convs.0.weight", "convs.2.weight"):
+        report["d_grad_rel_l2/" + n] = rel_l2(dgot[n], ref["d_grads_raw"][n])
+        assert report["d_grad_rel_l2/" + n] < 8e-2, f"{n}: rel L2 {report['d_grad_rel_l2/' + n]}"
+    for n, lim in (("decoder.linear.weight", 8e-2), ("decoder.linear.bias", 8e-2), ("decoder.lstm.weight_hh_l0", 8e-2),
+                   ("decoder.lstm.weight_ih_l0", 8e-2), ("decoder.embed.weight", 8e-2), ("encoder.linear.weight", 1e-1), ("encoder.bn.weight", 1e-1),
+                   ("encoder.bn.bias", 1e-1)):
+        report["g_grad_rel_l2/" + n] = rel_l2(ggot[n], ref["g_grads_raw"][n])
+        assert report["g_grad_rel_l2/" + n] < lim, f"{n}: rel L2 {report['g_grad_rel_l2/' + n]} (limit {lim})"
+    print("cfg2 composed parity:", json.dumps(report))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", "cfg2_parity.json"), "w") as fh:
+            json.dump(report, fh, indent=1)
+    except OSError:
+        pass

@@ -109,3 +109,16 @@ def test_product_path_has_no_oracle_import():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_noise_seeds_differ_across_data_parallel_ranks():
+    """Replicas share weights and the torch seed (main.py seeds every rank alike) but must not share Gumbel noise / dropout masks."""
+    import torch
+    from gan_image_captioning_amd.generator import _SeedStream
+    torch.manual_seed(1008)
+    a, b = _SeedStream(), _SeedStream()
+    b.rank = 1
+    sa, sb = [a.next() for _ in range(4)], [b.next() for _ in range(4)]
+    assert len(set(sa + sb)) == 8
+    c = _SeedStream()
+    assert [c.next() for _ in range(4)] == sa            # same rank, same seed -> same stream

@@ -161,3 +161,44 @@ def test_losses_and_temperature_scalars():
     with pytest.raises(Exception):
         O.get_fixed_temperature(100, 1, 30, "bogus")
     assert math.isclose(O.get_fixed_temperature(100, 25, 50, "exp"), 10.0, rel_tol=1e-12)
+
+
+def test_api_corners_match_reference():
+    """sample(states=...), Decoder.forward differentiated, Discriminator(dropout=0.5): golden api_tiny.npz (reference's own classes)."""
+    import numpy as np
+    g = Golden("api_tiny")
+    m = g.meta
+    P = g.group("p0/")
+    gp = {k: v for k, v in P.items() if k.startswith("decoder.")}
+    dp = {k: v for k, v in P.items() if not k.startswith("decoder.")}
+    leaf = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    f, h0, c0 = (g.t(k).clone().requires_grad_(True) for k in ("feats", "h0", "c0"))
+    u = g.t("st/u")
+    probs, ids = O.decoder_sample(leaf, f, m["L"], m["T"], [u[t] for t in range(m["L"])], states=(h0, c0))
+    assert torch.equal(ids, g.t("st/ids"))
+    torch.testing.assert_close(probs, g.t("st/probs"), rtol=1e-4, atol=1e-7)
+    (probs * g.t("st/d_out")).sum().backward()
+    for got, key in ((f.grad, "st/d_feats"), (h0.grad, "st/d_h0"), (c0.grad, "st/d_c0")):
+        grad_close(got, g.t(key), key)
+    for k, w in g.group("st/grad/").items():
+        grad_close(leaf[k].grad, w, "st " + k)
+    # teacher-forced forward, differentiated
+    leaf = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    f = g.t("feats").clone().requires_grad_(True)
+    logits, _ = O.decoder_forward_tf(leaf, f, g.t("caps"), g.t("tf/lengths").tolist(), m["T"], pretrain=True)
+    torch.testing.assert_close(logits, g.t("tf/logits"), rtol=1e-4, atol=1e-6)
+    (logits * g.t("tf/d_logits")).sum().backward()
+    grad_close(f.grad, g.t("tf/d_feats"), "tf d_feats")
+    for k, w in g.group("tf/grad/").items():
+        grad_close(leaf[k].grad, w, "tf " + k)
+    # discriminator with dropout p = 0.5
+    F = sum(m["nf"])
+    mask = torch.from_numpy(np.unpackbits(g.z["dr/mask"], axis=-1)[..., :F].astype(np.float32))
+    dleaf = {k: v.clone().requires_grad_(True) for k, v in dp.items()}
+    inp = g.t("dr/inp").clone().requires_grad_(True)
+    logit = O.disc_forward(dleaf, inp, mask, m["R"], dropout_p=m["dropout"])
+    torch.testing.assert_close(logit, g.t("dr/logits"), rtol=1e-4, atol=1e-6)
+    (logit * g.t("dr/d_logits")).sum().backward()
+    grad_close(inp.grad, g.t("dr/d_inp"), "dr d_inp")
+    for k, w in g.group("dr/grad/").items():
+        grad_close(dleaf[k].grad, w, "dr " + k)
