@@ -96,19 +96,30 @@ def conv_times_in_step(inst, step, n_steps=4):
     plan = inst.gen.encoder.resnet._plan
     was = plan.use_graph
     plan.use_graph = False
-    for k in range(2):
-        step(k)
-    torch.cuda.synchronize()
-    plan.conv_trace = []
-    for k in range(n_steps):
-        step(k)
-    torch.cuda.synchronize()
-    trace, plan.conv_trace = plan.conv_trace, None
+
+    def collect(fn, n):
+        for k in range(2):
+            fn(k)
+        torch.cuda.synchronize()
+        plan.conv_trace = []
+        for k in range(n):
+            fn(k)
+        torch.cuda.synchronize()
+        trace, plan.conv_trace = plan.conv_trace, None
+        res = {}
+        for name, a, b in trace:
+            res.setdefault(name, []).append(a.elapsed_time(b))
+        return res
+
+    in_step = collect(step, n_steps)
+    # calibration: the same event brackets around the same launches with the chip otherwise idle.  bracket - back-to-back replay of
+    # that layer (roofline_probe measures it) = what one bracket adds (event + dispatch latency); it is subtracted per layer there.
+    enc = inst.gen.encoder
+    N, S = inst.args.adv_train_batch_size, inst.args.image_size
+    imgs = torch.randn(N, 3, S, S, device=inst.args.device)
+    alone = collect(lambda k: enc.trunk_features(imgs, True), n_steps)
     plan.use_graph = was
-    out = {}
-    for name, a, b in trace:
-        out.setdefault(name, []).append(a.elapsed_time(b))
-    return out
+    return {"in_step": in_step, "alone": alone}
 
 
 def roofline_probe(inst, args, cgan, step=None):

@@ -43,7 +43,11 @@ class DecoderShadow(C.Structure):
 
 class DecoderState(C.Structure):
     _fields_ = [("xh", c_void_p * MAX_LAYERS), ("gates", c_void_p * MAX_LAYERS), ("c", c_void_p * MAX_LAYERS),
-                ("hout", c_void_p), ("logits", c_void_p), ("gpre", c_void_p)]
+                ("hout", c_void_p), ("logits", c_void_p), ("gpre", c_void_p), ("part", c_void_p)]
+
+
+class DecoderSampleOpts(C.Structure):
+    _fields_ = [("h0", c_void_p), ("c0", c_void_p), ("force_ids", c_void_p), ("force_len", c_void_p), ("no_state", C.c_int32)]
 
 
 class DecoderBwdWs(C.Structure):
@@ -98,7 +102,7 @@ _SIGNATURES = {
     "gic_disc_bwd_ws_bytes": (C.c_int, [_P(DiscDims), c_void_p]),
     "gic_decoder_prepare": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), c_void_p]),
     "gic_decoder_sample_fwd": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), _P(DecoderState), c_void_p,
-                                         c_void_p, C.c_uint64, C.c_float, C.c_int, c_void_p, c_void_p, c_void_p]),
+                                         c_void_p, C.c_uint64, C.c_float, C.c_int, c_void_p, c_void_p, _P(DecoderSampleOpts), c_void_p]),
     "gic_decoder_forward_tf": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), _P(DecoderState), c_void_p, c_void_p,
                                          c_void_p, C.c_int, c_void_p, C.c_uint64, C.c_float, C.c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p]),
@@ -163,8 +167,8 @@ def load() -> C.CDLL:
             raise GicError(f"{path} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = argtypes
-    if lib.gic_abi_version() != 1:
-        raise GicError(f"ABI version mismatch: library {lib.gic_abi_version()}, binding 1")
+    if lib.gic_abi_version() != 2:
+        raise GicError(f"ABI version mismatch: library {lib.gic_abi_version()}, binding 2")
     _lib = lib
     return lib
 

@@ -6,7 +6,10 @@
 // [L*B, Din+H] operand; the vocabulary side (probs, d_probs, d_logits, hout) is
 // batch-major [B, L, .] like the tensors the reference returns.  The pointwise kernels
 // bridge the two with explicit strides.
+#include <stdlib.h>
+
 #include "../../include/gicap.h"
+#include "decoder_step.h"
 #include "kernels.h"
 
 namespace gic {
@@ -273,18 +276,88 @@ int check_dims(const gic_decoder_dims* d, Ctx& c) {
   return GIC_OK;
 }
 
+// slot 0 of the recurrent buffers: initial (h, c) -- zeros, or the caller's states (generator.py:55,61) -- and features -> x_0
+int init_slot0(const Ctx& c, const gic_decoder_state* st, const float* features, const gic_decoder_sample_opts* opt, hipStream_t stream) {
+  const int B = c.B, E = c.E, H = c.H;
+  for (int l = 0; l < c.NL; ++l) {
+    if (opt && opt->h0) {
+      if (l > 0) GIC_PROPAGATE(fill_zero(st->xh[l], (size_t)B * c.ldx(l) * c.asz(), stream));
+      GIC_PROPAGATE(cast2d(opt->h0 + (long)l * B * H, DT_F32, H, (char*)st->xh[l] + (size_t)c.din(l) * c.asz(), c.dt, c.ldx(l), B, H, stream));
+    } else {
+      GIC_PROPAGATE(fill_zero(st->xh[l], (size_t)B * c.ldx(l) * c.asz(), stream));
+    }
+    if (opt && opt->c0) GIC_PROPAGATE(cast2d(opt->c0 + (long)l * B * H, DT_F32, H, st->c[l], DT_F32, H, B, H, stream));
+    else GIC_PROPAGATE(fill_zero(st->c[l], (size_t)B * H * sizeof(float), stream));
+  }
+  return cast2d(features, DT_F32, E, st->xh[0], c.dt, c.ldx(0), B, E, stream);
+}
+
+// The roll-out as two fused launches per step + one finishing launch (decoder_step.h).
+template <typename TA>
+int sample_fwd_fused(const Ctx& c, const gic_decoder_params* P, const gic_decoder_shadow* S, const gic_decoder_state* st,
+                     const float* noise_u, uint64_t seed, float temperature, int pretrain, void* out, int64_t* ids,
+                     const gic_decoder_sample_opts* opt, hipStream_t stream) {
+  const int B = c.B, L = c.L, V = c.V, H = c.H, NL = c.NL;
+  const int nblk = cdiv(V, kVocabTile);
+  const long per = (long)L * B * nblk;
+  float* part_m = st->part;
+  float* part_s = st->part + per;
+  int* part_i = (int*)(st->part + 2 * per);
+  const bool keep = !(opt && opt->no_state);
+  for (int t = 0; t < L; ++t) {
+    for (int l = 0; l < NL; ++l) {
+      const long ld = c.ldx(l);
+      LstmStepArgs a;
+      a.xh_t = (TA*)st->xh[l] + (long)t * B * ld;
+      a.xh_next = (TA*)st->xh[l] + (long)(t + 1) * B * ld;
+      a.wcat = S->wcat[l]; a.bsum = S->bsum[l];
+      a.c_prev = st->c[l] + (long)t * B * H; a.c_new = st->c[l] + (long)(t + 1) * B * H;
+      a.gates = keep ? st->gates[l] + (long)t * B * 4 * H : nullptr;
+      if (l + 1 < NL) { a.h_up = (TA*)st->xh[l + 1] + (long)t * B * c.ldx(l + 1); a.ld_up = c.ldx(l + 1); }
+      if (l + 1 == NL && st->hout) { a.h_out = (TA*)st->hout + (long)t * H; a.ld_out = (long)L * H; }
+      a.B = B; a.H = H; a.din = c.din(l); a.ldx = ld;
+      if (l == 0 && t > 0) {
+        a.gather = 1; a.embed = P->embed; a.V = V;
+        a.part_m = part_m + (long)(t - 1) * B * nblk; a.part_i = part_i + (long)(t - 1) * B * nblk; a.nblk = nblk;
+        if (opt && opt->force_ids) { a.force_ids = opt->force_ids; a.force_stride = L; a.force_len = opt->force_len; }
+        a.tprev = t - 1;
+      }
+      GIC_PROPAGATE(lstm_step(a, c.dt, stream));
+    }
+    VocabStepArgs v;
+    const int l = NL - 1;
+    v.h = (TA*)st->xh[l] + (long)(t + 1) * B * c.ldx(l) + c.din(l); v.ldh = c.ldx(l);
+    v.wout = S->wout; v.bias = P->b_out;
+    v.u = noise_u ? noise_u + (long)t * B * V : nullptr;
+    v.seed = seed; v.rng_stream = (uint64_t)t; v.temperature = temperature; v.pretrain = pretrain;
+    v.out = out ? (void*)((TA*)out + (long)t * V) : nullptr; v.out_stride = (long)L * V;
+    v.part_m = part_m + (long)t * B * nblk; v.part_s = part_s + (long)t * B * nblk; v.part_i = part_i + (long)t * B * nblk;
+    v.nblk = nblk; v.B = B; v.V = V; v.H = H;
+    GIC_PROPAGATE(vocab_step(v, c.dt, stream));
+  }
+  SampleFinishArgs f;
+  f.part_m = part_m; f.part_s = part_s; f.part_i = part_i; f.nblk = nblk; f.B = B; f.L = L; f.V = V; f.E = c.E;
+  f.pretrain = pretrain; f.out = out; f.ids = ids;
+  if (opt && opt->force_ids) { f.force_ids = opt->force_ids; f.force_len = opt->force_len; }
+  if (keep) { f.embed = P->embed; f.xh0 = st->xh[0]; f.ldx0 = c.ldx(0); }
+  return sample_finish(f, c.dt, stream);
+}
+
 template <typename TA>
 int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_shadow* S, const gic_decoder_state* st,
                  const float* features, const float* noise_u, uint64_t seed, float temperature, int pretrain,
-                 void* out, int64_t* ids, hipStream_t stream) {
+                 void* out, int64_t* ids, const gic_decoder_sample_opts* opt, hipStream_t stream) {
   const int B = c.B, L = c.L, V = c.V, E = c.E, H = c.H, NL = c.NL;
   const int pw_grid = cdiv((long)B * H, 256);
-  // slot 0: zero hidden / cell state, features -> layer-0 input
-  for (int l = 0; l < NL; ++l) {
-    GIC_PROPAGATE(fill_zero(st->xh[l], (size_t)B * c.ldx(l) * c.asz(), stream));
-    GIC_PROPAGATE(fill_zero(st->c[l], (size_t)B * H * sizeof(float), stream));
-  }
-  GIC_PROPAGATE(cast2d(features, DT_F32, E, st->xh[0], c.dt, c.ldx(0), B, E, stream));
+  GIC_PROPAGATE(init_slot0(c, st, features, opt, stream));
+  // up to a few hundred rows the per-step products are latency-bound: the fused step kernels; beyond that (Monte-Carlo
+  // roll-out batches) they are large GEMMs and the generic 128-row-tile kernels are the efficient form
+  static const int fused_max_rows = [] { const char* e = getenv("GIC_FUSED_ROLLOUT_MAX_ROWS"); return e ? atoi(e) : 512; }();
+  if (st->part && B <= fused_max_rows && decoder_step_supported(c.dt, V, E, H, NL))
+    return sample_fwd_fused<TA>(c, P, S, st, noise_u, seed, temperature, pretrain, out, ids, opt, stream);
+  GIC_CHECK_ARG(out && st->logits && st->gpre, "decoder_sample_fwd: the unfused path needs out, state->logits and state->gpre");
+  GIC_CHECK_ARG(!(opt && (opt->force_ids || opt->no_state)), "decoder_sample_fwd: forced trajectories / stateless roll-outs need the fused step kernels "
+                "(V %% 4 == 0, E %% 8 == 0, H %% 8 == 0, state->part)");
 
   for (int t = 0; t < L; ++t) {
     for (int l = 0; l < NL; ++l) {
@@ -561,6 +634,7 @@ int gic_decoder_state_bytes(const gic_decoder_dims* dims, uint64_t* out) {
   out[3 * GIC_MAX_LAYERS + 0] = B * L * H * a;
   out[3 * GIC_MAX_LAYERS + 1] = B * (uint64_t)c.V * 4;
   out[3 * GIC_MAX_LAYERS + 2] = B * 4 * H * 4;
+  out[3 * GIC_MAX_LAYERS + 3] = (uint64_t)decoder_step_part_floats(c.B, c.L, c.V) * 4;
   return GIC_OK;
 }
 
@@ -606,16 +680,19 @@ int gic_decoder_prepare(const gic_decoder_dims* dims, const gic_decoder_params* 
 
 int gic_decoder_sample_fwd(const gic_decoder_dims* dims, const gic_decoder_params* P, const gic_decoder_shadow* S,
                            const gic_decoder_state* st, const float* features, const float* noise_u, uint64_t seed,
-                           float temperature, int pretrain, void* out, int64_t* ids, void* stream) {
+                           float temperature, int pretrain, void* out, int64_t* ids, const gic_decoder_sample_opts* opt,
+                           void* stream) {
   Ctx c;
   GIC_PROPAGATE(check_dims(dims, c));
-  GIC_CHECK_ARG(P && S && st && features && out && ids, "decoder_sample_fwd: null argument");
-  GIC_CHECK_ARG(st->hout && st->logits && st->gpre, "decoder_sample_fwd: null state buffer");
+  GIC_CHECK_ARG(P && S && st && features && ids, "decoder_sample_fwd: null argument");
+  const bool keep = !(opt && opt->no_state);
+  GIC_CHECK_ARG(!keep || (st->hout && out), "decoder_sample_fwd: out / state->hout may be NULL only for a stateless roll-out (opts->no_state)");
+  GIC_CHECK_ARG(!(opt && opt->force_len && !opt->force_ids), "decoder_sample_fwd: force_len without force_ids");
   for (int l = 0; l < c.NL; ++l)
-    GIC_CHECK_ARG(st->xh[l] && st->gates[l] && st->c[l] && S->wcat[l] && S->bsum[l], "decoder_sample_fwd: null layer %d buffer", l);
+    GIC_CHECK_ARG(st->xh[l] && (st->gates[l] || !keep) && st->c[l] && S->wcat[l] && S->bsum[l], "decoder_sample_fwd: null layer %d buffer", l);
   if (c.dt == DT_F32)
-    return sample_fwd_t<float>(c, P, S, st, features, noise_u, seed, temperature, pretrain, out, ids, (hipStream_t)stream);
-  return sample_fwd_t<bf16_t>(c, P, S, st, features, noise_u, seed, temperature, pretrain, out, ids, (hipStream_t)stream);
+    return sample_fwd_t<float>(c, P, S, st, features, noise_u, seed, temperature, pretrain, out, ids, opt, (hipStream_t)stream);
+  return sample_fwd_t<bf16_t>(c, P, S, st, features, noise_u, seed, temperature, pretrain, out, ids, opt, (hipStream_t)stream);
 }
 
 int gic_decoder_sample_bwd(const gic_decoder_dims* dims, const gic_decoder_params* P, const gic_decoder_shadow* S,

@@ -27,6 +27,35 @@ def _check(status, what):
     L.check(status, what)
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
+class _ConvTimer:
+    __slots__ = ("trace", "name", "a")
+
+    def __init__(self, trace, name):
+        self.trace, self.name = trace, name
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.a.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        b = torch.cuda.Event(enable_timing=True)
+        b.record(torch.cuda.current_stream())
+        self.trace.append((self.name, self.a, b))
+        return False
+
+
 class _ConvStep:
     __slots__ = ("conv", "bn", "cin", "cout", "k", "stride", "pad", "stats_off", "fused_in", "w", "name")
 
@@ -171,21 +200,10 @@ class TrunkPlan:
 
     # ---------------------------------------------------------------- kernels
     def _traced(self, name: str):
-        """Context that brackets ONE convolution launch with HIP events on its launch stream while ``conv_trace`` is a list."""
-        plan = self
-
-        class _T:
-            def __enter__(self_t):
-                if plan.conv_trace is not None:
-                    self_t.a = torch.cuda.Event(enable_timing=True)
-                    self_t.a.record(torch.cuda.current_stream())
-
-            def __exit__(self_t, *exc):
-                if plan.conv_trace is not None:
-                    b = torch.cuda.Event(enable_timing=True)
-                    b.record(torch.cuda.current_stream())
-                    plan.conv_trace.append((name, self_t.a, b))
-        return _T()
+        """Context that brackets ONE convolution launch with HIP events on its launch stream while ``conv_trace`` is a list;
+        a shared no-op object otherwise (nothing is allocated on the normal path: a hipGraph capture must not see garbage
+        collection free device objects)."""
+        return _NULL_CTX if self.conv_trace is None else _ConvTimer(self.conv_trace, name)
 
     def _conv(self, s: _ConvStep, x: torch.Tensor, y: torch.Tensor, stats: Optional[torch.Tensor], N, H, W, cin=None, kw=None, pad=None):
         st = None if stats is None else stats.data_ptr() + 4 * s.stats_off
@@ -400,10 +418,12 @@ def head_bwd(dtype, saved, weight, gamma, d_out, grads=None):
 def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None, in_step=None):
     """The dominant kernel of the step = the implicit-GEMM convolution kernel (every trunk convolution is a launch of it).
 
-    ``in_step`` = {layer name: [ms per launch, ...]} measured by bench.py with HIP events around every convolution launch on
-    its launch stream WHILE the real train step runs on the other streams (TrunkPlan.conv_trace): `achieved` / `frac` are
-    the algorithmic FLOPs of all launches / the summed in-step durations.  The isolated replay of each distinct layer shape
-    (hot caches, nothing else on the chip) is kept beside it under "isolated_replay"."""
+    ``in_step`` = {"in_step": {layer: [ms per launch, ...]}, "alone": {...}} measured by bench.py with HIP events around every
+    convolution launch on its launch stream WHILE the real train step runs on the other streams (TrunkPlan.conv_trace), and the
+    same brackets with the chip otherwise idle.  A bracket adds event + dispatch latency to the kernel's duration; per layer
+    that overhead = bracket("alone") - the back-to-back replay of the layer (measured here), and it is subtracted from the in-step
+    bracket.  `achieved` / `frac` = algorithmic FLOPs of all launches / the summed corrected in-step durations.  The isolated
+    replay (hot caches, nothing else on the chip) is kept beside it under "isolated_replay"."""
     import sys
     plan = encoder.resnet._plan
     N, S = args.adv_train_batch_size, args.image_size
@@ -417,9 +437,10 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None, 
             seen[key] = [event_time_ms(lambda: plan.replay(s, xi, yo, b["stats"], N, H, W, kw, prev), 5, stream), 0, macs,
                          s.name + (" [bn+relu on load]" if key[5] else ""), 0.0]
         seen[key][1] += 1
-        if in_step and s.name in in_step:
-            v = in_step[s.name]
-            seen[key][4] += sum(v) / len(v)
+        if in_step and s.name in in_step["in_step"]:
+            v, a0 = in_step["in_step"][s.name], in_step["alone"].get(s.name)
+            overhead = max(0.0, sum(a0) / len(a0) - seen[key][0]) if a0 else 0.0
+            seen[key][4] += max(seen[key][0], sum(v) / len(v) - overhead)
     total_ms = total_flops = bound_us = total_bytes = step_ms = 0.0
     launches = 0
     layers = []
@@ -448,7 +469,8 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None, 
     return {"kernel": "conv kernels of the ResNet trunk (tile8_kernel<CONV, EPI_BNSTATS> family): implicit-GEMM convolution, bf16 16x16x32 MFMA, 8 waves, "
                       f"LDS-DMA ring, {launches} launches/step",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(achieved / peak_tflops, 4),
-            "measured": ("HIP events around every convolution launch on its launch stream while the train step runs on the other streams"
+            "measured": ("HIP events around every convolution launch on its launch stream while the train step runs on the other streams, "
+                         "minus the per-layer bracket overhead (bracket with the chip idle - back-to-back replay)"
                          if step_ms > 0 else "isolated replay of each layer shape under HIP events"),
             "traffic": pmc_traffic, "ms_per_launch": round(use_ms / launches, 5), "launches_per_step": launches,
             "ms_per_step": round(use_ms, 4), "algorithmic_gflop_per_step": round(total_flops / 1e9, 1),

@@ -216,6 +216,19 @@ class DecoderEngine:
             "hout": torch.empty(B, Lc, self.H, device=dev, dtype=self.act),
             "logits": torch.empty(B, self.V, device=dev, dtype=f32),
             "gpre": torch.empty(B, 4 * self.H, device=dev, dtype=f32),
+            # per-tile softmax partials of the fused step kernels ([3][L][B][ceil(V/64)], decoder_step.h)
+            "part": torch.empty(3 * Lc * B * ((self.V + 63) // 64), device=dev, dtype=f32),
+        }
+
+    def alloc_rollout_state(self, B: int, Lc: int, dev) -> Dict[str, object]:
+        """State of an inference roll-out (``no_state``): recurrent buffers only, nothing saved for a backward pass."""
+        f32 = torch.float32
+        return {
+            "xh": [torch.empty(Lc + 1, B, self.ldx(l), device=dev, dtype=self.act) for l in range(self.NL)],
+            "gates": [None] * self.NL,
+            "c": [torch.empty(Lc + 1, B, self.H, device=dev, dtype=f32) for _ in range(self.NL)],
+            "hout": None, "logits": None, "gpre": None,
+            "part": torch.empty(3 * Lc * B * ((self.V + 63) // 64), device=dev, dtype=f32),
         }
 
     def _state_struct(self, st) -> L.DecoderState:
@@ -224,6 +237,7 @@ class DecoderEngine:
         s.gates = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in st["gates"]])
         s.c = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in st["c"]])
         s.hout, s.logits, s.gpre = ptr(st["hout"]), ptr(st["logits"]), ptr(st["gpre"])
+        s.part = ptr(st.get("part"))
         return s
 
     def alloc_bwd_ws(self, B: int, Lc: int, dev) -> Dict[str, object]:
@@ -243,9 +257,13 @@ class DecoderEngine:
         return g
 
     def sample_fwd(self, params, features: torch.Tensor, Lc: int, temperature: float, pretrain: bool = False,
-                   noise_u: Optional[torch.Tensor] = None, seed: int = 0, state=None, out=None, ids=None):
+                   noise_u: Optional[torch.Tensor] = None, seed: int = 0, state=None, out=None, ids=None,
+                   states=None, force_ids: Optional[torch.Tensor] = None, force_len: Optional[torch.Tensor] = None,
+                   ids_only: bool = False):
+        """``states`` = (h0, c0), each f32 [NL, B, H] (generator.py:55,61).  ``force_ids`` int64 [B, L] (+ ``force_len`` int32 [B]):
+        trajectory to follow (gicap.h).  ``ids_only``: inference roll-out, returns (None, ids, state) and saves nothing for backward."""
         self.check_params(params)
-        require_gpu(features, noise_u)
+        require_gpu(features, noise_u, force_ids, force_len)
         B = features.shape[0]
         if features.shape != (B, self.E) or features.dtype != torch.float32:
             raise ValueError(f"features must be float32 [B,{self.E}], got {tuple(features.shape)} {features.dtype}")
@@ -256,15 +274,42 @@ class DecoderEngine:
                 raise ValueError(f"noise_u must be float32 [L={Lc},B={B},V={self.V}]")
             noise_u = noise_u.contiguous()
         self.prepare(params)
-        st = state if state is not None else self.alloc_state(B, Lc, dev)
-        out = out if out is not None else torch.empty(B, Lc, self.V, device=dev, dtype=self.act)
+        if state is not None:
+            st = state
+        else:
+            st = self.alloc_rollout_state(B, Lc, dev) if ids_only else self.alloc_state(B, Lc, dev)
+        if not ids_only:
+            out = out if out is not None else torch.empty(B, Lc, self.V, device=dev, dtype=self.act)
         ids = ids if ids is not None else torch.empty(B, Lc, device=dev, dtype=torch.int64)
+        opts = None
+        keep = []
+        if states is not None or force_ids is not None or ids_only:
+            opts = L.DecoderSampleOpts()
+            if states is not None:
+                h0, c0 = (t.detach().to(torch.float32).contiguous() for t in states)
+                if tuple(h0.shape) != (self.NL, B, self.H) or tuple(c0.shape) != (self.NL, B, self.H):
+                    raise ValueError(f"states must be (h0, c0), each [num_layers={self.NL}, B={B}, H={self.H}]")
+                require_gpu(h0, c0)
+                opts.h0, opts.c0 = ptr(h0), ptr(c0)
+                keep += [h0, c0]
+            if force_ids is not None:
+                if tuple(force_ids.shape) != (B, Lc) or force_ids.dtype != torch.int64:
+                    raise ValueError(f"force_ids must be int64 [B={B}, L={Lc}]")
+                force_ids = force_ids.contiguous()
+                opts.force_ids = ptr(force_ids)
+                if force_len is not None:
+                    force_len = force_len.to(torch.int32).contiguous()
+                    if tuple(force_len.shape) != (B,):
+                        raise ValueError("force_len must hold one prefix length per caption")
+                    opts.force_len = ptr(force_len)
+                keep += [force_ids, force_len]
+            opts.no_state = int(bool(ids_only))
         d = self.dims(B, Lc)
         L.check(L.load().gic_decoder_sample_fwd(
             C.byref(d), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
-            ptr(features), ptr(noise_u), int(seed) & (2 ** 64 - 1), float(temperature), int(bool(pretrain)), ptr(out), ptr(ids),
-            stream_ptr()), "gic_decoder_sample_fwd")
-        return out, ids, st
+            ptr(features), ptr(noise_u), int(seed) & (2 ** 64 - 1), float(temperature), int(bool(pretrain)), ptr(out) if not ids_only else None,
+            ptr(ids), C.byref(opts) if opts is not None else None, stream_ptr()), "gic_decoder_sample_fwd")
+        return (None if ids_only else out), ids, st
 
     def forward_tf(self, params, features: torch.Tensor, caps: torch.Tensor, lengths, temperature: float, pretrain: bool = False,
                    noise_u: Optional[torch.Tensor] = None, seed: int = 0):
@@ -321,6 +366,13 @@ class DecoderEngine:
             C.byref(w), ptr(out), ptr(ids), ptr(d_out), float(temperature), int(bool(pretrain)),
             C.byref(self._pstruct(grads[:-1], L.DecoderGrads, grads[-1])), int(phases), stream_ptr()), "gic_decoder_sample_bwd")
         return grads
+
+    def state_grads(self, ws):
+        """(d_h0, d_c0), each f32 [NL, B, H], from the backward workspace of the sample_bwd call that just ran: slot 0 of the
+        recurrent input-gradient buffers holds d[x_0 | h_-1], the cell-gradient carry ends at d c_-1."""
+        d_h0 = torch.stack([ws["dxh"][l][0][:, self.din(l):] for l in range(self.NL)]).contiguous()
+        d_c0 = torch.stack([ws["dc"][l] for l in range(self.NL)]).contiguous()
+        return d_h0, d_c0
 
     def _cast_like(self, t: torch.Tensor) -> torch.Tensor:
         t = t.contiguous()

@@ -101,11 +101,13 @@ class _LinearParams(nn.Module):
 # ------------------------------------------------------------------------------------------ decoder
 class _SampleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, temperature, pretrain, max_len, noise_u, seed, features, *params):
+    def forward(ctx, eng, temperature, pretrain, max_len, noise_u, seed, h0, c0, features, *params):
         dparams = [p.detach() for p in params]
-        out, ids, st = eng.sample_fwd(dparams, features.detach().float(), max_len, temperature, pretrain, noise_u, seed)
+        states = None if h0 is None else (h0.detach(), c0.detach())
+        out, ids, st = eng.sample_fwd(dparams, features.detach().float(), max_len, temperature, pretrain, noise_u, seed, states=states)
         ctx.eng, ctx.temperature, ctx.pretrain = eng, temperature, pretrain
         ctx.st, ctx.dparams = st, dparams
+        ctx.has_states = states is not None
         ctx.save_for_backward(out, ids)
         ctx.mark_non_differentiable(ids)
         return out, ids
@@ -113,9 +115,13 @@ class _SampleFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out, _d_ids):
         out, ids = ctx.saved_tensors
-        grads = ctx.eng.sample_bwd(ctx.dparams, ctx.st, out, ids, d_out, ctx.temperature, ctx.pretrain)
+        ws = ctx.eng.alloc_bwd_ws(ids.shape[0], ids.shape[1], out.device)
+        grads = ctx.eng.sample_bwd(ctx.dparams, ctx.st, out, ids, d_out, ctx.temperature, ctx.pretrain, ws=ws)
         ctx.st = None
-        return (None, None, None, None, None, None, grads[-1], *grads[:-1])
+        d_h0 = d_c0 = None
+        if ctx.has_states:        # gradients into the initial states: slot 0 of the recurrent input-gradient buffers
+            d_h0, d_c0 = ctx.eng.state_grads(ws)
+        return (None, None, None, None, None, None, d_h0, d_c0, grads[-1], *grads[:-1])
 
 
 class Decoder(nn.Module):
@@ -146,11 +152,12 @@ class Decoder(nn.Module):
     def sample(self, features, states=None, pretrain=False, max_caption_len=34, noise_u=None):
         """Greedy Gumbel-softmax roll-out (generator.py:55-81): returns (outputs [B,L,V], ids int64 [B,L]).
         Gradients flow through ``outputs`` to the decoder parameters and ``features``; never through ``ids``."""
-        if states is not None:
-            raise NotImplementedError("sample(states=...) is not supported: training.py never passes initial states")
+        h0 = c0 = None
+        if states is not None:          # (h0, c0), each [num_layers, B, H], as nn.LSTM takes them (generator.py:61)
+            h0, c0 = states
         seed = 0 if noise_u is not None else SEEDS.next()
         return _SampleFn.apply(self.engine(), float(self.temperature), bool(pretrain), int(max_caption_len), noise_u, seed,
-                               features, *self.param_list())
+                               h0, c0, features, *self.param_list())
 
     def forward(self, features, caps, lengths, pretrain=False, noise_u=None):
         """Teacher-forced decode (generator.py:39-53): inputs [features ; embed(caps)] packed with ``lengths``; returns

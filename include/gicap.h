@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GIC_ABI_VERSION 1
+#define GIC_ABI_VERSION 2
 #define GIC_MAX_LAYERS 4
 #define GIC_MAX_CONVS 8
 
@@ -108,6 +108,8 @@ typedef struct gic_decoder_state {
   void* hout;                            /* act [B, L, H] last layer's h, batch-major (vocab GEMM operand) */
   float* logits;                         /* scratch [B, V] */
   float* gpre;                           /* scratch [B, 4H] */
+  float* part;                           /* scratch [3][L][B][ceil(V/64)]: per-tile softmax partials of the fused step kernels
+                                            (max, sum of exp, first maximal index).  NULL selects the unfused launches. */
 } gic_decoder_state;
 
 typedef struct gic_decoder_bwd_ws {      /* scratch for backward (caller-owned) */
@@ -119,7 +121,7 @@ typedef struct gic_decoder_bwd_ws {      /* scratch for backward (caller-owned) 
 } gic_decoder_bwd_ws;
 
 /* Byte size of every buffer of the caller-owned structs above for `dims`, in field order (per-layer arrays take GIC_MAX_LAYERS
- * entries, 0 for unused layers): gic_decoder_state -> xh[], gates[], c[], hout, logits, gpre (3*GIC_MAX_LAYERS + 3 values);
+ * entries, 0 for unused layers): gic_decoder_state -> xh[], gates[], c[], hout, logits, gpre, part (3*GIC_MAX_LAYERS + 4 values);
  * gic_decoder_bwd_ws -> dlogits, dhout, dgates[], dxh[], dc[] (2 + 3*GIC_MAX_LAYERS values).  Host-only: no GPU needed. */
 int gic_decoder_state_bytes(const gic_decoder_dims* dims, uint64_t* out);
 int gic_decoder_bwd_ws_bytes(const gic_decoder_dims* dims, uint64_t* out);
@@ -127,13 +129,26 @@ int gic_decoder_bwd_ws_bytes(const gic_decoder_dims* dims, uint64_t* out);
 int gic_decoder_prepare(const gic_decoder_dims* dims, const gic_decoder_params* params,
                         const gic_decoder_shadow* shadow, void* stream);
 
+/* Optional arguments of gic_decoder_sample_fwd (NULL = none). */
+typedef struct gic_decoder_sample_opts {
+  const float* h0;                       /* [NL,B,H] initial hidden state: sample(features, states=(h0, c0)), generator.py:55,61; NULL = zeros */
+  const float* c0;                       /* [NL,B,H] initial cell state; NULL = zeros */
+  const int64_t* force_ids;              /* [B,L] trajectory to FOLLOW: where forced, step t feeds embed(force_ids[b,t]) to step t+1 and
+                                            returns it in ids (out is computed as usual).  Prefixes of Monte-Carlo roll-outs; parity tests. */
+  const int32_t* force_len;              /* [B] number of leading steps that are forced per caption; NULL = all L */
+  int32_t no_state;                      /* != 0: inference roll-out -- nothing is saved for a backward pass: state->gates / hout and
+                                            `out` may be NULL (ids only) */
+} gic_decoder_sample_opts;
+
 /* features [B,E] f32.  noise_u: explicit U[0,1) draws [L,B,V] f32 (generator.py:86-90 order) or NULL to
  * draw on device with Philox(seed, step).  pretrain != 0: generator.py:63-66 (out = raw logits, feedback =
- * argmax).  out: act [B,L,V] (probabilities or logits).  ids: int64 [B,L]. */
+ * argmax).  out: act [B,L,V] (probabilities or logits).  ids: int64 [B,L].
+ * With state->part set and V % 4 == 0, E % 8 == 0, H % 8 == 0 a step is two fused launches (gates product + LSTM cell;
+ * vocabulary product + Gumbel + per-tile softmax partials) and the probabilities are normalised by one launch at the end. */
 int gic_decoder_sample_fwd(const gic_decoder_dims* dims, const gic_decoder_params* params,
                            const gic_decoder_shadow* shadow, const gic_decoder_state* state,
                            const float* features, const float* noise_u, uint64_t seed, float temperature,
-                           int pretrain, void* out, int64_t* ids, void* stream);
+                           int pretrain, void* out, int64_t* ids, const gic_decoder_sample_opts* opts, void* stream);
 
 /* Decoder.forward, the teacher-forced decode (src/generator.py:39-53; forward only: the reference's training never calls it).
  * dims->L = T = caption length + 1 time steps: step 0 is fed `features`, step t > 0 embed(caps[b, t-1]) (caps int64 [B, T-1]).

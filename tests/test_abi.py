@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.library_path())
     for name in declared_symbols():
         assert hasattr(lib, name), f"libgicap.so does not export {name}"
-    assert _lib.load().gic_abi_version() == 1
+    assert _lib.load().gic_abi_version() == 2
 
 
 def test_argument_validation_returns_status_not_crash():
@@ -47,7 +47,8 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(_lib.DecoderDims) == 7 * 4
     assert ctypes.sizeof(_lib.DecoderParams) == (3 + 4 * _lib.MAX_LAYERS) * P
     assert ctypes.sizeof(_lib.DecoderGrads) == (4 + 4 * _lib.MAX_LAYERS) * P
-    assert ctypes.sizeof(_lib.DecoderState) == (3 + 3 * _lib.MAX_LAYERS) * P
+    assert ctypes.sizeof(_lib.DecoderState) == (4 + 3 * _lib.MAX_LAYERS) * P
+    assert ctypes.sizeof(_lib.DecoderSampleOpts) == 5 * P          # 4 pointers + int32 (padded)
     assert ctypes.sizeof(_lib.DiscDims) == (6 + 2 * _lib.MAX_CONVS + 3) * 4 + 4       # + float drop_p
     assert ctypes.sizeof(_lib.DiscParams) == (7 + 2 * _lib.MAX_CONVS) * P
 
@@ -72,10 +73,10 @@ def test_workspace_size_queries_match_the_host_allocations():
         st, ws = dec.alloc_state(B, Lc, "meta"), dec.alloc_bwd_ws(B, Lc, "meta")
         nb = lambda t: t.numel() * t.element_size()
         d = dec.dims(B, Lc)
-        out = (ctypes.c_uint64 * (3 * ML + 3))()
+        out = (ctypes.c_uint64 * (3 * ML + 4))()
         assert lib.gic_decoder_state_bytes(ctypes.byref(d), out) == 0
         want = [nb(t) for t in st["xh"]] + [0] * (ML - NL) + [nb(t) for t in st["gates"]] + [0] * (ML - NL) + \
-               [nb(t) for t in st["c"]] + [0] * (ML - NL) + [nb(st["hout"]), nb(st["logits"]), nb(st["gpre"])]
+               [nb(t) for t in st["c"]] + [0] * (ML - NL) + [nb(st["hout"]), nb(st["logits"]), nb(st["gpre"]), nb(st["part"])]
         assert list(out) == want
         out = (ctypes.c_uint64 * (2 + 3 * ML))()
         assert lib.gic_decoder_bwd_ws_bytes(ctypes.byref(d), out) == 0

@@ -565,3 +565,166 @@ def test_no_cpu_fallback(E):
     from gan_image_captioning_amd._lib import GicError
     with pytest.raises(GicError):
         E.gemm(torch.zeros(4, 4), torch.zeros(4, 4), torch.zeros(4, 4), 4, 4, 4, 4, 4, 4)
+
+
+# ------------------------------------------------------------------------------------------ fused roll-out step kernels
+FUSED_SHAPES = [  # (B, L, V, E, H, NL)
+    (5, 6, 52, 8, 24, 2), (70, 4, 132, 16, 40, 1), (8, 10, 64, 32, 512, 1), (64, 3, 10000, 64, 128, 1), (3, 5, 4, 8, 8, 3),
+]
+
+
+def _rand_decoder(V, Em, H, NL, seed, scale=6.0):
+    g = torch.Generator().manual_seed(seed)
+    gp = O.make_gen_params(V, Em, H, NL, g)
+    return {k: v * scale for k, v in gp.items()}, g
+
+
+@pytest.mark.parametrize("shape", FUSED_SHAPES)
+def test_fused_rollout_f32_matches_oracle(E, dev, shape):
+    """lstm_step / vocab_step / sample_finish (decoder_step.hip) in fp32 parity mode against the oracle (pinned to the reference's
+    Decoder.sample by the goldens): ids exact, probabilities rtol 1e-4, and -- through the backward pass that consumes the saved
+    state (x rows, hidden states, gates, cell states) -- every gradient.  Initial states (generator.py:55,61) on the first two."""
+    from gan_image_captioning_amd import _lib
+    B, Lc, V, Em, H, NL = shape
+    gp, g = _rand_decoder(V, Em, H, NL, sum(shape))
+    names = dec_param_names(NL)
+    feats = torch.randn(B, Em, generator=g) * 0.3
+    us = [torch.empty(B, V).uniform_(0, 1, generator=g) for _ in range(Lc)]
+    d_out = torch.randn(B, Lc, V, generator=g)
+    states = None
+    if shape in FUSED_SHAPES[:2]:
+        states = (torch.randn(NL, B, H, generator=g) * 0.5, torch.randn(NL, B, H, generator=g) * 0.5)
+    T = 1.3
+    leaf = {k: gp[k].clone().requires_grad_(True) for k in names}
+    f_leaf = feats.clone().requires_grad_(True)
+    st_leaf = None if states is None else tuple(t.clone().requires_grad_(True) for t in states)
+    probs, ids_ref = O.decoder_sample(leaf, f_leaf, Lc, T, us, states=st_leaf)
+    (probs * d_out).sum().backward()
+    eng = E.DecoderEngine(V, Em, H, NL, 0)
+    assert bool(_lib.load())            # the library is loaded: no other implementation exists
+    params = dec_params(gp, dev)
+    dstates = None if states is None else tuple(t.to(dev) for t in states)
+    out, ids, st = eng.sample_fwd(params, feats.to(dev), Lc, T, noise_u=torch.stack(us).to(dev), states=dstates)
+    assert st["part"] is not None
+    ws = eng.alloc_bwd_ws(B, Lc, dev)
+    grads = eng.sample_bwd(params, st, out, ids, d_out.to(dev), T, ws=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(ids.cpu(), ids_ref), "token ids differ from the oracle"
+    close(out, probs, rtol=1e-4, atol_scale=1e-6, what="probs")
+    for n, gt in zip(names, grads[:-1]):
+        close(gt, leaf[n].grad, rtol=2e-3, atol_scale=1e-4, what=n)
+    close(grads[-1], f_leaf.grad, rtol=2e-3, atol_scale=1e-4, what="d_features")
+    if states is not None:
+        d_h0, d_c0 = eng.state_grads(ws)
+        close(d_h0, st_leaf[0].grad, rtol=2e-3, atol_scale=1e-4, what="d_h0")
+        close(d_c0, st_leaf[1].grad, rtol=2e-3, atol_scale=1e-4, what="d_c0")
+    # the same call through the unfused launches (no partials scratch): identical ids, probabilities to rounding
+    st2 = eng.alloc_state(B, Lc, dev)
+    st2["part"] = None
+    out2, ids2, _ = eng.sample_fwd(params, feats.to(dev), Lc, T, noise_u=torch.stack(us).to(dev), states=dstates, state=st2)
+    torch.cuda.synchronize()
+    assert torch.equal(ids2, ids)
+    close(out2, out, rtol=1e-4, atol_scale=1e-6, what="fused vs unfused probs")
+    # pretrain mode (generator.py:63-66): raw logits out, greedy feedback
+    logits, ids_p = O.decoder_sample(gp, feats, Lc, 1.0, None, pretrain=True, states=states)
+    outp, idsp, _ = eng.sample_fwd(params, feats.to(dev), Lc, 1.0, pretrain=True, states=dstates)
+    torch.cuda.synchronize()
+    assert torch.equal(idsp.cpu(), ids_p)
+    close(outp, logits, rtol=1e-4, atol_scale=1e-5, what="pretrain logits")
+
+
+def test_fused_rollout_forced_prefix_and_ids_only(E, dev):
+    """force_ids / force_len: rows follow a given prefix and continue on their own argmax (the Monte-Carlo roll-out primitive);
+    ids_only: the same ids with nothing else written."""
+    B, Lc, V, Em, H, NL = 9, 7, 48, 8, 32, 2
+    gp, g = _rand_decoder(V, Em, H, NL, 77)
+    feats = torch.randn(B, Em, generator=g) * 0.3
+    us = [torch.empty(B, V).uniform_(0, 1, generator=g) for _ in range(Lc)]
+    forced = torch.randint(0, V, (B, Lc), generator=g)
+    flen = torch.tensor([0, 1, 2, 3, 4, 5, 6, 7, 3], dtype=torch.int32)
+    T = 2.0
+    # oracle: per row, follow the prefix for flen steps, then the argmax -- emulate with a two-pass force (ids of the free pass differ per row)
+    want_ids = torch.empty(B, Lc, dtype=torch.long)
+    want_probs = torch.empty(B, Lc, V)
+    for b in range(B):
+        cur = forced[b:b + 1].clone()
+        for t in range(int(flen[b]), Lc):          # extend the trajectory one free step at a time
+            p, _ = O.decoder_sample(gp, feats[b:b + 1], Lc, T, [u[b:b + 1] for u in us], force_ids=cur)
+            cur[0, t] = p[0, t].argmax()
+        p, _ = O.decoder_sample(gp, feats[b:b + 1], Lc, T, [u[b:b + 1] for u in us], force_ids=cur)
+        want_ids[b], want_probs[b] = cur[0], p[0]
+    eng = E.DecoderEngine(V, Em, H, NL, 0)
+    params = dec_params(gp, dev)
+    u = torch.stack(us).to(dev)
+    out, ids, _ = eng.sample_fwd(params, feats.to(dev), Lc, T, noise_u=u, force_ids=forced.to(dev), force_len=flen.to(dev))
+    _, ids2, _ = eng.sample_fwd(params, feats.to(dev), Lc, T, noise_u=u, force_ids=forced.to(dev), force_len=flen.to(dev), ids_only=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ids.cpu(), want_ids)
+    assert torch.equal(ids2, ids)
+    close(out, want_probs, rtol=1e-4, atol_scale=1e-6, what="probs on the forced trajectory")
+
+
+def test_fused_rollout_bf16_close_to_oracle(E, dev):
+    """bf16 fused step kernels at the benchmark's decoder shapes (B=64, V=10000, E=H=512), 6 steps: ids match-rate >= 0.95 against
+    the fp32 oracle; probabilities compared on the GPU's own trajectory (relative L2 <= 3e-2)."""
+    B, Lc, V, Em, H, NL = 64, 6, 10000, 512, 512, 1
+    g = torch.Generator().manual_seed(5)
+    gp = O.make_gen_params(V, Em, H, NL, g)
+    feats = torch.randn(B, Em, generator=g) * 0.3
+    us = [torch.empty(B, V).uniform_(0, 1, generator=g) for _ in range(Lc)]
+    T = 1.7
+    eng = E.DecoderEngine(V, Em, H, NL, 1)
+    out, ids, _ = eng.sample_fwd(dec_params(gp, dev), feats.to(dev), Lc, T, noise_u=torch.stack(us).to(dev))
+    torch.cuda.synchronize()
+    _, ids_ref = O.decoder_sample(gp, feats, Lc, T, us)
+    match = float((ids.cpu() == ids_ref).float().mean())
+    assert match >= 0.95, match
+    probs, _ = O.decoder_sample(gp, feats, Lc, T, us, force_ids=ids.cpu())
+    assert rel_l2(out.float(), probs) < 3e-2
+    assert float((out.float().sum(-1) - 1).abs().max()) < 2e-2       # rows are normalised
+
+
+def test_api_corners_match_reference_golden(E, dev):
+    """Module-API corners against the reference's own outputs (golden api_tiny.npz): Decoder.sample(states=...) with gradients into
+    the states (generator.py:55,61) and Discriminator(dropout=0.5) (discriminator.py:10,30)."""
+    import numpy as np
+    g = Golden("api_tiny")
+    m = g.meta
+    P = g.group("p0/")
+    gp = {k: v for k, v in P.items() if k.startswith("decoder.")}
+    dp = {k: v for k, v in P.items() if not k.startswith("decoder.")}
+    eng = _decoder(E, gp, 0)
+    params = dec_params(gp, dev)
+    B, Lc = m["B"], m["L"]
+    out, ids, st = eng.sample_fwd(params, g.t("feats").to(dev), Lc, m["T"], noise_u=g.t("st/u").to(dev),
+                                  states=(g.t("h0").to(dev), g.t("c0").to(dev)))
+    ws = eng.alloc_bwd_ws(B, Lc, dev)
+    grads = eng.sample_bwd(params, st, out, ids, g.t("st/d_out").to(dev), m["T"], ws=ws)
+    d_h0, d_c0 = eng.state_grads(ws)
+    torch.cuda.synchronize()
+    assert torch.equal(ids.cpu(), g.t("st/ids"))
+    close(out, g.t("st/probs"), rtol=1e-4, atol_scale=1e-6, what="probs")
+    want = g.group("st/grad/")
+    for n, gt in zip(dec_param_names(m["NL"]), grads[:-1]):
+        close(gt, want[n], rtol=2e-3, atol_scale=1e-4, what=n)
+    close(grads[-1], g.t("st/d_feats"), rtol=2e-3, atol_scale=1e-4, what="d_features")
+    close(d_h0, g.t("st/d_h0"), rtol=2e-3, atol_scale=1e-4, what="d_h0")
+    close(d_c0, g.t("st/d_c0"), rtol=2e-3, atol_scale=1e-4, what="d_c0")
+    # discriminator with dropout p = 0.5
+    F = sum(m["nf"])
+    mask = torch.from_numpy(np.unpackbits(g.z["dr/mask"], axis=-1)[..., :F].astype(np.float32))
+    den = E.DiscEngine(m["V"], m["De"], m["R"], m["fs"], m["nf"], 0, dropout=m["dropout"])
+    dparams = disc_params(dp, dev)
+    soft = den.soft_input(g.t("dr/inp").to(dev))
+    lg, dst = den.fwd(dparams, soft, None, True, mask.to(dev))
+    dgr, d_inp = den.bwd(dparams, dst, soft, None, True, g.t("dr/d_logits").to(dev), True, True)
+    torch.cuda.synchronize()
+    close(lg, g.t("dr/logits"), rtol=1e-4, atol_scale=1e-5, what="logits (dropout 0.5)")
+    close_mostly(d_inp, g.t("dr/d_inp"), 2e-3, 1e-4, "d_inp", 1e-2, 1.5e-2)
+    wantd = g.group("dr/grad/")
+    up = set(disc_param_names(len(m["nf"]))[:1 + 2 * len(m["nf"])])
+    for n, gt in zip(disc_param_names(len(m["nf"])), dgr):
+        if n in up:
+            close_mostly(gt, wantd[n], 2e-3, 1e-4, n, 1e-2, 1.5e-2)
+        else:
+            close(gt, wantd[n], rtol=2e-3, atol_scale=1e-4, what=n, atol_abs=1e-6)
