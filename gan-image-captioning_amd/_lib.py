@@ -109,6 +109,7 @@ _SIGNATURES = {
     "gic_decoder_sample_bwd": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), _P(DecoderState),
                                          _P(DecoderBwdWs), c_void_p, c_void_p, c_void_p, C.c_float, C.c_int,
                                          _P(DecoderGrads), C.c_int, c_void_p]),
+    "gic_debug_decoder_step": (None, [C.c_int]),
     "gic_embedding_fwd": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, c_void_p]),
     "gic_embedding_bwd": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int, c_void_p]),
     "gic_disc_prepare": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), c_void_p]),
@@ -132,7 +133,8 @@ _SIGNATURES = {
     "gic_colsum": (C.c_int, [c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, c_void_p, C.c_int, c_void_p]),
     "gic_gan_losses": (C.c_int, [C.c_int, c_void_p, c_void_p, c_void_p, C.c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
-    "gic_xent": (C.c_int, [c_void_p, C.c_int, C.c_int64, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gic_xent": (C.c_int, [c_void_p, C.c_int, C.c_int64, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gic_rollout_rewards": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),
     "gic_clip_adam_partials": (C.c_int64, [C.c_int64]),
     "gic_clip_adam": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
                                 C.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -72,6 +72,12 @@ _NATIVE = [
     ("--encoder-arch", str, "resnet18", "trunk shape: resnet18 (the reference's) or resnet50", {"choices": ["resnet18", "resnet50"]}),
     ("--step-impl", str, "fused", "adversarial step driver: fused (direct kernel sequence) or autograd (module API)",
      {"choices": ["fused", "autograd"]}),
+    ("--adv-mode", str, "relgan", "generator update of the adversarial loop: relgan = Gumbel-softmax relaxation through D (the reference, "
+                                  "training.py:144-169); seqgan = policy gradient with Monte-Carlo roll-outs scored by D", {"choices": ["relgan", "seqgan"]}),
+    ("--mc-rollouts", int, 16, "Monte-Carlo roll-outs per prefix (--adv-mode seqgan)"),
+    ("--decoder", str, "lstm", "caption decoder: lstm (the reference, generator.py:27-96) or attention (visual attention over the trunk's "
+                               "feature map, Show-Attend-Tell style; needs --conditional-gan 1)", {"choices": ["lstm", "attention"]}),
+    ("--attn-dim", int, 512, "width of the additive-attention hidden layer (--decoder attention)"),
     ("--real-as-ids", int, 1, "feed real captions to D as token ids (gather) instead of a dense one-hot", {"choices": [0, 1]}),
     ("--synthetic", int, 0, "use synthetic (image, caption) batches instead of COCO", {"choices": [0, 1]}),
     ("--synthetic-batches", int, 8, "batches per epoch of the synthetic dataset"),

@@ -35,8 +35,10 @@ __global__ void lstm_pointwise_fwd_kernel(const float* __restrict__ gpre, const 
   const float o_ = sigmoidf_(g[3 * H + j]);
   const float c = f_ * c_prev[idx] + i_ * g_;
   const float h = o_ * tanhf(c);
-  float* go = gates + (long)b * 4 * H;
-  go[j] = i_; go[H + j] = f_; go[2 * H + j] = g_; go[3 * H + j] = o_;
+  if (gates) {
+    float* go = gates + (long)b * 4 * H;
+    go[j] = i_; go[H + j] = f_; go[2 * H + j] = g_; go[3 * H + j] = o_;
+  }
   c_new[idx] = c;
   h_next[(long)b * ld_next + j] = from_f32<TA>(h);
   if (h_up) h_up[(long)b * ld_up + j] = from_f32<TA>(h);
@@ -74,12 +76,13 @@ template <typename TA>
 __global__ __launch_bounds__(256) void gumbel_softmax_argmax_kernel(
     float* __restrict__ logits, const float* __restrict__ u, uint64_t seed, uint64_t rng_stream, float temperature,
     int pretrain, TA* __restrict__ out, long out_row_stride, int64_t* __restrict__ ids, long ids_stride,
-    const float* __restrict__ embed, TA* __restrict__ x_next, long ld_x, int V, int E) {
+    const float* __restrict__ embed, TA* __restrict__ x_next, long ld_x, int V, int E,
+    const int64_t* __restrict__ force_ids, const int32_t* __restrict__ force_len, int t) {
   __shared__ float red[16];
   __shared__ int red_i[16];
   const int b = blockIdx.x, tid = threadIdx.x;
   float* row = logits + (long)b * V;
-  TA* orow = out + (long)b * out_row_stride;
+  TA* orow = out ? out + (long)b * out_row_stride : nullptr;
   const float eps = 1e-10f;
 
   // pass 1: y, row max
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void gumbel_softmax_argmax_kernel(
   for (int v = tid; v < V; v += 256) {
     const float y = row[v];
     const float p = expf(y - mx) / sm;
-    orow[v] = from_f32<TA>(pretrain ? y : p);
+    if (orow) orow[v] = from_f32<TA>(pretrain ? y : p);
     if (p > best) { best = p; best_i = v; }
   }
 #pragma unroll
@@ -128,6 +131,10 @@ __global__ __launch_bounds__(256) void gumbel_softmax_argmax_kernel(
   best = red[0]; best_i = red_i[0];
   for (int w = 1; w < 4; ++w)
     if (red[w] > best || (red[w] == best && red_i[w] < best_i)) { best = red[w]; best_i = red_i[w]; }
+  if (force_ids && (!force_len || t < force_len[b])) {       // forced trajectory (gicap.h, gic_decoder_sample_opts)
+    const long f = force_ids[(long)b * ids_stride];
+    best_i = (int)(f < 0 ? 0 : (f >= V ? V - 1 : f));
+  }
   if (tid == 0) ids[(long)b * ids_stride] = best_i;
   if (x_next)
     for (int e = tid; e < E; e += 256) x_next[(long)b * ld_x + e] = from_f32<TA>(embed[(long)best_i * E + e]);
@@ -141,12 +148,13 @@ template <typename TA, int QPT, bool FAST>
 __global__ __launch_bounds__(1024) void gumbel_softmax_argmax_reg_kernel(
     const float* __restrict__ logits, const float* __restrict__ u, uint64_t seed, uint64_t rng_stream, float temperature,
     int pretrain, TA* __restrict__ out, long out_row_stride, int64_t* __restrict__ ids, long ids_stride,
-    const float* __restrict__ embed, TA* __restrict__ x_next, long ld_x, int V, int E) {
+    const float* __restrict__ embed, TA* __restrict__ x_next, long ld_x, int V, int E,
+    const int64_t* __restrict__ force_ids, const int32_t* __restrict__ force_len, int t) {
   __shared__ float red[16];
   __shared__ int red_i[16];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* row = logits + (long)b * V;
-  TA* orow = out + (long)b * out_row_stride;
+  TA* orow = out ? out + (long)b * out_row_stride : nullptr;
   const float eps = 1e-10f;
   const int nq = V >> 2;
   float y[QPT][4];
@@ -203,11 +211,13 @@ __global__ __launch_bounds__(1024) void gumbel_softmax_argmax_reg_kernel(
         p[k] = ex[e][k] / sm;
         if (p[k] > best) { best = p[k]; best_i = 4 * q + k; }
       }
-      TA o4[4];
+      if (orow) {
+        TA o4[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) o4[k] = from_f32<TA>(pretrain ? y[e][k] : p[k]);
-      if constexpr (sizeof(TA) == 4) *(float4*)(orow + 4 * q) = *(const float4*)o4;
-      else *(uint2*)(orow + 4 * q) = *(const uint2*)o4;
+        for (int k = 0; k < 4; ++k) o4[k] = from_f32<TA>(pretrain ? y[e][k] : p[k]);
+        if constexpr (sizeof(TA) == 4) *(float4*)(orow + 4 * q) = *(const float4*)o4;
+        else *(uint2*)(orow + 4 * q) = *(const uint2*)o4;
+      }
     }
   }
 #pragma unroll
@@ -222,6 +232,10 @@ __global__ __launch_bounds__(1024) void gumbel_softmax_argmax_reg_kernel(
   best = red[0]; best_i = red_i[0];
   for (int w = 1; w < 16; ++w)
     if (red[w] > best || (red[w] == best && red_i[w] < best_i)) { best = red[w]; best_i = red_i[w]; }
+  if (force_ids && (!force_len || t < force_len[b])) {
+    const long f = force_ids[(long)b * ids_stride];
+    best_i = (int)(f < 0 ? 0 : (f >= V ? V - 1 : f));
+  }
   if (tid == 0) ids[(long)b * ids_stride] = best_i;
   if (x_next)
     for (int e = tid; e < E; e += 1024) x_next[(long)b * ld_x + e] = from_f32<TA>(embed[(long)best_i * E + e]);
@@ -302,7 +316,8 @@ int sample_fwd_fused(const Ctx& c, const gic_decoder_params* P, const gic_decode
   const long per = (long)L * B * nblk;
   float* part_m = st->part;
   float* part_s = st->part + per;
-  int* part_i = (int*)(st->part + 2 * per);
+  unsigned long long* rowkey = (unsigned long long*)(st->part + ((2 * per + 1) & ~1l));      // [L][B], 8-byte aligned
+  GIC_PROPAGATE(fill_zero(rowkey, (size_t)L * B * sizeof(unsigned long long), stream));    // atomicMax targets start below every key
   const bool keep = !(opt && opt->no_state);
   for (int t = 0; t < L; ++t) {
     for (int l = 0; l < NL; ++l) {
@@ -318,7 +333,7 @@ int sample_fwd_fused(const Ctx& c, const gic_decoder_params* P, const gic_decode
       a.B = B; a.H = H; a.din = c.din(l); a.ldx = ld;
       if (l == 0 && t > 0) {
         a.gather = 1; a.embed = P->embed; a.V = V;
-        a.part_m = part_m + (long)(t - 1) * B * nblk; a.part_i = part_i + (long)(t - 1) * B * nblk; a.nblk = nblk;
+        a.rowkey = rowkey + (long)(t - 1) * B;
         if (opt && opt->force_ids) { a.force_ids = opt->force_ids; a.force_stride = L; a.force_len = opt->force_len; }
         a.tprev = t - 1;
       }
@@ -331,12 +346,12 @@ int sample_fwd_fused(const Ctx& c, const gic_decoder_params* P, const gic_decode
     v.u = noise_u ? noise_u + (long)t * B * V : nullptr;
     v.seed = seed; v.rng_stream = (uint64_t)t; v.temperature = temperature; v.pretrain = pretrain;
     v.out = out ? (void*)((TA*)out + (long)t * V) : nullptr; v.out_stride = (long)L * V;
-    v.part_m = part_m + (long)t * B * nblk; v.part_s = part_s + (long)t * B * nblk; v.part_i = part_i + (long)t * B * nblk;
+    v.part_m = part_m + (long)t * B * nblk; v.part_s = part_s + (long)t * B * nblk; v.rowkey = rowkey + (long)t * B;
     v.nblk = nblk; v.B = B; v.V = V; v.H = H;
     GIC_PROPAGATE(vocab_step(v, c.dt, stream));
   }
   SampleFinishArgs f;
-  f.part_m = part_m; f.part_s = part_s; f.part_i = part_i; f.nblk = nblk; f.B = B; f.L = L; f.V = V; f.E = c.E;
+  f.part_m = part_m; f.part_s = part_s; f.rowkey = rowkey; f.nblk = nblk; f.B = B; f.L = L; f.V = V; f.E = c.E;
   f.pretrain = pretrain; f.out = out; f.ids = ids;
   if (opt && opt->force_ids) { f.force_ids = opt->force_ids; f.force_len = opt->force_len; }
   if (keep) { f.embed = P->embed; f.xh0 = st->xh[0]; f.ldx0 = c.ldx(0); }
@@ -355,9 +370,10 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
   static const int fused_max_rows = [] { const char* e = getenv("GIC_FUSED_ROLLOUT_MAX_ROWS"); return e ? atoi(e) : 512; }();
   if (st->part && B <= fused_max_rows && decoder_step_supported(c.dt, V, E, H, NL))
     return sample_fwd_fused<TA>(c, P, S, st, noise_u, seed, temperature, pretrain, out, ids, opt, stream);
-  GIC_CHECK_ARG(out && st->logits && st->gpre, "decoder_sample_fwd: the unfused path needs out, state->logits and state->gpre");
-  GIC_CHECK_ARG(!(opt && (opt->force_ids || opt->no_state)), "decoder_sample_fwd: forced trajectories / stateless roll-outs need the fused step kernels "
-                "(V %% 4 == 0, E %% 8 == 0, H %% 8 == 0, state->part)");
+  GIC_CHECK_ARG(st->logits && st->gpre, "decoder_sample_fwd: the unfused path needs state->logits and state->gpre");
+  const bool keep = !(opt && opt->no_state);
+  const int64_t* f_ids = opt ? opt->force_ids : nullptr;
+  const int32_t* f_len = opt ? opt->force_len : nullptr;
 
   for (int t = 0; t < L; ++t) {
     for (int l = 0; l < NL; ++l) {
@@ -369,10 +385,10 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
       g.M = B; g.N = 4 * H; g.K = (int)ld; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.bias = S->bsum[l];
       GIC_PROPAGATE(gemm(g, stream));
       TA* h_up = (l + 1 < NL) ? (TA*)st->xh[l + 1] + (long)t * B * c.ldx(l + 1) : nullptr;
-      TA* h_out = (l + 1 == NL) ? (TA*)st->hout + (long)t * H : nullptr;
+      TA* h_out = (l + 1 == NL && st->hout) ? (TA*)st->hout + (long)t * H : nullptr;
       hipLaunchKernelGGL((lstm_pointwise_fwd_kernel<TA>), dim3(pw_grid), dim3(256), 0, stream,
                          (const float*)st->gpre, (const float*)(st->c[l] + (long)t * B * H),
-                         st->gates[l] + (long)t * B * 4 * H, st->c[l] + (long)(t + 1) * B * H,
+                         keep ? st->gates[l] + (long)t * B * 4 * H : (float*)nullptr, st->c[l] + (long)(t + 1) * B * H,
                          xh_n + c.din(l), ld, h_up, h_up ? c.ldx(l + 1) : 0, h_out, (long)L * H, B, H);
       GIC_CHECK_LAUNCH("lstm_pointwise_fwd");
     }
@@ -387,19 +403,20 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
     }
     TA* x_next = (TA*)st->xh[0] + (long)(t + 1) * B * c.ldx(0);
     const float* u_t = noise_u ? noise_u + (long)t * B * V : nullptr;
+    TA* out_t = out ? (TA*)out + (long)t * V : nullptr;
     constexpr bool kFast = sizeof(TA) == 2;
     if (V % 4 == 0 && V <= 4096) {
       hipLaunchKernelGGL((gumbel_softmax_argmax_reg_kernel<TA, 1, kFast>), dim3(B), dim3(1024), 0, stream, (const float*)st->logits,
-                         u_t, seed, (uint64_t)t, temperature, pretrain, (TA*)out + (long)t * V, (long)L * V, ids + t, (long)L,
-                         P->embed, x_next, c.ldx(0), V, E);
+                         u_t, seed, (uint64_t)t, temperature, pretrain, out_t, (long)L * V, ids + t, (long)L,
+                         P->embed, x_next, c.ldx(0), V, E, f_ids ? f_ids + t : nullptr, f_len, t);
     } else if (V % 4 == 0 && V <= 16384) {
       hipLaunchKernelGGL((gumbel_softmax_argmax_reg_kernel<TA, 4, kFast>), dim3(B), dim3(1024), 0, stream, (const float*)st->logits,
-                         u_t, seed, (uint64_t)t, temperature, pretrain, (TA*)out + (long)t * V, (long)L * V, ids + t, (long)L,
-                         P->embed, x_next, c.ldx(0), V, E);
+                         u_t, seed, (uint64_t)t, temperature, pretrain, out_t, (long)L * V, ids + t, (long)L,
+                         P->embed, x_next, c.ldx(0), V, E, f_ids ? f_ids + t : nullptr, f_len, t);
     } else {
       hipLaunchKernelGGL((gumbel_softmax_argmax_kernel<TA>), dim3(B), dim3(256), 0, stream, st->logits, u_t, seed, (uint64_t)t,
-                         temperature, pretrain, (TA*)out + (long)t * V, (long)L * V, ids + t, (long)L, P->embed, x_next,
-                         c.ldx(0), V, E);
+                         temperature, pretrain, out_t, (long)L * V, ids + t, (long)L, P->embed, x_next,
+                         c.ldx(0), V, E, f_ids ? f_ids + t : nullptr, f_len, t);
     }
     GIC_CHECK_LAUNCH("gumbel_softmax_argmax");
   }
@@ -434,8 +451,41 @@ int sample_bwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
   }
   if (!(phases & GIC_DECODER_BWD_RECURRENT)) return GIC_OK;
   // 3. BPTT
+  bool fused = decoder_step_supported(c.dt, 4, 8, H, NL) && H % 2 == 0 && B <= 512;
+  for (int l = 0; l < NL; ++l) fused = fused && S->wcat_t[l] != nullptr;
+  for (int l = 0; l < NL; ++l) GIC_PROPAGATE(fill_zero(ws->dc[l], (size_t)B * H * sizeof(float), stream));
+  if (fused) {
+    // one launch per (step, layer): the recurrent (and, below the top layer, the upper layer's input) gradient product fused with
+    // the cell's pointwise backward (decoder_step.h); the x-side input gradients leave the serial chain as ONE product afterwards
+    for (int t = L - 1; t >= 0; --t) {
+      for (int l = NL - 1; l >= 0; --l) {
+        LstmBwdStepArgs a;
+        if (l == NL - 1) { a.dh_above = ws->dhout + (long)t * H; a.ld_above = (long)L * H; }
+        else { a.dg_up = (TA*)ws->dgates[l + 1] + (long)t * B * 4 * H; a.w_up = S->wcat_t[l + 1]; }
+        if (t + 1 < L) { a.dg_next = (TA*)ws->dgates[l] + (long)(t + 1) * B * 4 * H; a.w_rec = (TA*)S->wcat_t[l] + (long)c.din(l) * 4 * H; }
+        a.gates = st->gates[l] + (long)t * B * 4 * H;
+        a.c_prev = st->c[l] + (long)t * B * H; a.c_cur = st->c[l] + (long)(t + 1) * B * H;
+        a.dc_state = ws->dc[l]; a.dgates = (TA*)ws->dgates[l] + (long)t * B * 4 * H;
+        a.B = B; a.H = H;
+        GIC_PROPAGATE(lstm_bwd_step(a, c.dt, stream));
+      }
+    }
+    {  // d x_t of layer 0 for every step: dX0 [L*B, E] = dgates_0 [L*B, 4H] . W_ih_0, into the x columns of dxh[0] slots 0..L-1
+      GemmDesc g;
+      g.A = ws->dgates[0]; g.lda = 4 * H; g.a_kc = 1; g.B = S->wcat_t[0]; g.ldb = 4 * H; g.b_kc = 1;
+      g.C = ws->dxh[0]; g.ldc = c.ldx(0); g.M = (int)BL; g.N = E; g.K = 4 * H; g.in_dtype = c.dt; g.out_dtype = DT_F32;
+      GIC_PROPAGATE(gemm(g, stream));
+    }
+    if (phases & GIC_DECODER_BWD_STATE_GRADS) {   // d h_-1 = dgates_0 . W_hh into the h columns of slot 0 (gradient of the initial state)
+      for (int l = 0; l < NL; ++l) {
+        GemmDesc g;
+        g.A = ws->dgates[l]; g.lda = 4 * H; g.a_kc = 1; g.B = (TA*)S->wcat_t[l] + (long)c.din(l) * 4 * H; g.ldb = 4 * H; g.b_kc = 1;
+        g.C = ws->dxh[l] + c.din(l); g.ldc = c.ldx(l); g.M = B; g.N = H; g.K = 4 * H; g.in_dtype = c.dt; g.out_dtype = DT_F32;
+        GIC_PROPAGATE(gemm(g, stream));
+      }
+    }
+  } else {
   for (int l = 0; l < NL; ++l) {
-    GIC_PROPAGATE(fill_zero(ws->dc[l], (size_t)B * H * sizeof(float), stream));
     // all L+1 slots at once: slot L is the zero gradient behind the last step, slots < L are split-K accumulators
     GIC_PROPAGATE(fill_zero(ws->dxh[l], (size_t)(L + 1) * B * c.ldx(l) * sizeof(float), stream));
   }
@@ -460,6 +510,7 @@ int sample_bwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
       g.M = B; g.N = (int)ld; g.K = 4 * H; g.in_dtype = c.dt; g.out_dtype = DT_F32;
       GIC_PROPAGATE(gemm(g, stream));
     }
+  }
   }
   // 4. batched weight gradients over all L*B rows
   for (int l = 0; l < NL; ++l) {
@@ -590,7 +641,8 @@ int forward_tf_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
     GIC_PROPAGATE(gemm(g, stream));
   }
   hipLaunchKernelGGL((gumbel_softmax_argmax_kernel<TA>), dim3((unsigned)rows), dim3(256), 0, stream, logits_ws, noise_u, seed, (uint64_t)0x7466,
-                     temperature, pretrain, (TA*)out, (long)V, ids_ws, (long)1, P->embed, (TA*)nullptr, (long)0, V, E);
+                     temperature, pretrain, (TA*)out, (long)V, ids_ws, (long)1, P->embed, (TA*)nullptr, (long)0, V, E,
+                     (const int64_t*)nullptr, (const int32_t*)nullptr, 0);
   GIC_CHECK_LAUNCH("gumbel_softmax (teacher forced)");
   for (int l = 0; l < NL; ++l) {
     GIC_PROPAGATE(cast2d((const TA*)st->xh[l] + (long)Tmax * B * c.ldx(l) + c.din(l), c.dt, c.ldx(l), h_n + (long)l * B * H, DT_F32, H, B, H, stream));
@@ -619,6 +671,8 @@ int gic_decoder_forward_tf(const gic_decoder_dims* dims, const gic_decoder_param
   return forward_tf_t<bf16_t>(c, P, S, st, features, caps, lengths, Tmax, noise_u, seed, temperature, pretrain, logits_ws, ids_ws, out,
                               h_n, c_n, (hipStream_t)stream);
 }
+
+void gic_debug_decoder_step(int v) { decoder_step_debug(v); }
 
 int gic_decoder_state_bytes(const gic_decoder_dims* dims, uint64_t* out) {
   Ctx c;
@@ -707,7 +761,7 @@ int gic_decoder_sample_bwd(const gic_decoder_dims* dims, const gic_decoder_param
     GIC_CHECK_ARG(ws->dgates[l] && ws->dxh[l] && ws->dc[l] && G->w_ih[l] && G->w_hh[l] && G->b_ih[l] && G->b_hh[l],
                   "decoder_sample_bwd: null layer %d buffer", l);
   hipStream_t stream = (hipStream_t)stream_;
-  GIC_CHECK_ARG(phases >= 1 && phases <= GIC_DECODER_BWD_ALL, "decoder_sample_bwd: phases must be 1, 2 or 3");
+  GIC_CHECK_ARG(phases >= 1 && phases <= (GIC_DECODER_BWD_ALL | GIC_DECODER_BWD_STATE_GRADS), "decoder_sample_bwd: phases must be a mask of 1 | 2 | 4");
   int s = (c.dt == DT_F32)
               ? sample_bwd_t<float>(c, P, S, st, ws, probs, ids, d_out, temperature, pretrain, G, phases, stream)
               : sample_bwd_t<bf16_t>(c, P, S, st, ws, probs, ids, d_out, temperature, pretrain, G, phases, stream);

@@ -34,8 +34,9 @@ struct LstmStepArgs {
   // layer 0, t > 0: x_t = embed[id_{t-1}], id = argmax over the previous step's partials (or the forced trajectory)
   int gather = 0;
   const float* embed = nullptr; int V = 0;
-  const float* part_m = nullptr; const int* part_i = nullptr; int nblk = 0;      // [B][nblk] of step t-1
+  const unsigned long long* rowkey = nullptr;      // [B] argmax keys of step t-1 (vocab_step's atomicMax; see row_key())
   const int64_t* force_ids = nullptr; long force_stride = 0; const int32_t* force_len = nullptr; int tprev = 0;
+  int dbg = 0;
 };
 
 struct VocabStepArgs {
@@ -47,12 +48,15 @@ struct VocabStepArgs {
   float temperature = 1.f;
   int pretrain = 0;
   void* out = nullptr; long out_stride = 0;  // act: out + b*out_stride + v (e or raw logits); null: ids only
-  float* part_m = nullptr; float* part_s = nullptr; int* part_i = nullptr; int nblk = 0;   // [B][nblk]
+  float* part_m = nullptr; float* part_s = nullptr; int nblk = 0;   // [B][nblk] per-tile max / sum of exp
+  unsigned long long* rowkey = nullptr;      // [B], zeroed by the caller: atomicMax of (ordered tile max, ~first maximal index)
   int B = 0, V = 0, H = 0;
+  int dbg = 0;
 };
 
 struct SampleFinishArgs {
-  const float* part_m = nullptr; const float* part_s = nullptr; const int* part_i = nullptr;   // [L][B][nblk]
+  const float* part_m = nullptr; const float* part_s = nullptr;   // [L][B][nblk]
+  const unsigned long long* rowkey = nullptr;                       // [L][B]
   int nblk = 0, B = 0, L = 0, V = 0, E = 0;
   int pretrain = 0;
   void* out = nullptr;                       // act [B, L, V] or null
@@ -61,9 +65,27 @@ struct SampleFinishArgs {
   const float* embed = nullptr; void* xh0 = nullptr; long ldx0 = 0;     // x rows of XH_0 slots 1..L-1 (for the weight gradient) or null
 };
 
+// One BPTT step of one layer (reverse of lstm_step): dh = dh_above + dgates_{t+1} W_hh [+ dgates^{l+1}_t W_ih^{l+1}], then the
+// cell's pointwise backward -> dgates_t, dc.  Tile = 16 batch rows x 16 hidden units per block, K (= 4H per segment) split over
+// the 8 waves, operands straight from L2 (the k-contiguous operand of W is the transposed weight image wcat_t).
+struct LstmBwdStepArgs {
+  const float* dh_above = nullptr; long ld_above = 0;   // f32 rows (top layer: dhout[b, t, :]) or null
+  const void* dg_next = nullptr;                        // act [B, 4H] dgates of step t+1, this layer (null at t = L-1)
+  const void* w_rec = nullptr;                          // act rows j of wcat_t (+ din rows): [H][4H], W_hh^T
+  const void* dg_up = nullptr;                          // act [B, 4H] dgates of step t, layer l+1 (null for the top layer)
+  const void* w_up = nullptr;                           // act rows j of the upper layer's wcat_t: [H][4H], W_ih^{l+1,T}
+  const float* gates = nullptr;                         // [B, 4H] post-activation i,f,g,o of step t
+  const float* c_prev = nullptr; const float* c_cur = nullptr;   // [B, H]
+  float* dc_state = nullptr;                            // [B, H] in/out
+  void* dgates = nullptr;                               // act [B, 4H] out
+  int B = 0, H = 0;
+};
+int lstm_bwd_step(const LstmBwdStepArgs& a, int dtype, hipStream_t stream);
+
 // true if the fused kernels take these shapes (else the caller uses the generic GEMM + pointwise launches)
 bool decoder_step_supported(int dtype, int V, int E, int H, int NL);
-size_t decoder_step_part_floats(int B, int L, int V);       // floats in the partials scratch ([3][L][B][nblk])
+size_t decoder_step_part_floats(int B, int L, int V);       // floats in the partials scratch: [2][L][B][nblk] floats + [L][B] 64-bit keys
+void decoder_step_debug(int v);                             // phase-ablation knob of tools/rollout_bench.py (0 = normal)
 int lstm_step(const LstmStepArgs& a, int dtype, hipStream_t stream);
 int vocab_step(const VocabStepArgs& a, int dtype, hipStream_t stream);
 int sample_finish(const SampleFinishArgs& a, int dtype, hipStream_t stream);

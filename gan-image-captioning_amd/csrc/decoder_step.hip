@@ -86,6 +86,14 @@ template <> __device__ __forceinline__ void mma<float>(f32x4& acc, const Frag<fl
   for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[s], b.v[s], acc, 0, 0, 0);
 }
 
+// 64-bit key whose unsigned order is (value ascending, index DESCENDING): atomicMax over the keys of a row = its first maximal index
+__device__ __forceinline__ unsigned long long row_key(float v, int idx) {
+  const unsigned int b = __float_as_uint(v);
+  const unsigned int ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  return ((unsigned long long)ord << 32) | (unsigned long long)(~(unsigned int)idx);
+}
+__device__ __forceinline__ int row_key_index(unsigned long long k) { return (int)(~(unsigned int)(k & 0xffffffffull)); }
+
 // (value, index) argmax across the 64 lanes: larger value wins, equal values -> smaller index (first maximal index)
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 #pragma unroll
@@ -96,45 +104,51 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
   }
 }
 
+// 16 bytes of the compute-dtype image of an f32 master row (embedding gather): 8 values in bf16, 4 in f32
+template <typename TA> __device__ __forceinline__ u32x4 chunk_from_f32(const float* p);
+template <> __device__ __forceinline__ u32x4 chunk_from_f32<float>(const float* p) { return *(gptr_u4)p; }
+template <> __device__ __forceinline__ u32x4 chunk_from_f32<bf16_t>(const float* p) {
+  const f32x4 a = *(gptr_f4)p, b = *(gptr_f4)(p + 4);
+  bf16x8 v;
+  v[0] = (bf16_t)a[0]; v[1] = (bf16_t)a[1]; v[2] = (bf16_t)a[2]; v[3] = (bf16_t)a[3];
+  v[4] = (bf16_t)b[0]; v[5] = (bf16_t)b[1]; v[6] = (bf16_t)b[2]; v[7] = (bf16_t)b[3];
+  return __builtin_bit_cast(u32x4, v);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // lstm_step: one LSTM layer, one time step, for 64 batch rows x 4 hidden units per block.
 //   gates[b, g*H + j] = sum_k [x_t | h_{t-1}][b, k] * Wcat[g*H + j, k] + bsum     (generator.py:61, nn.LSTM cell)
-// The 8 waves split K (each owns every 8th group of KPI 32-deep k-steps): operands go straight from L2 to registers (no
-// operand is shared between waves, so LDS staging would only add a hop), all of a wave's loads are in flight together,
-// and the K partials are summed through LDS by the 256 threads that then apply the cell nonlinearities.
-template <typename TA, int KPI>
-__global__ __launch_bounds__(512) void lstm_step_kernel(const LstmStepArgs a) {
-  __shared__ float red[8][kStepRows][17];
+// The activation tile [64, K] reaches LDS in K chunks of KC by COALESCED 16-byte loads (consecutive lanes = consecutive chunks
+// of one row; the x columns of a gathering step come from the f32 embedding rows, converted on the way) and MFMA fragments
+// are read from there: loading fragments straight from global memory touches 16 rows per wave instruction and is bound by
+// the texture addresser (measured 3x slower).  The 16 weight rows of the block are few enough to go straight to fragments.
+// The 8 waves split the k-steps of a chunk; their partial sums meet in LDS (the staging area, reused) and 256 threads apply the
+// cell nonlinearities.
+template <typename TA>
+__global__ __launch_bounds__(512) void lstm_step_kernel(const LstmStepArgs a, const int KC) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ls_smem[];
   __shared__ int ids_s[kStepRows];
+  constexpr int SZ = sizeof(TA), VE = 16 / SZ;
+  const int hs = KC * SZ + 16;                              // LDS row stride: 16-byte skew against bank conflicts
+  unsigned char* sA = ls_smem;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int j0 = blockIdx.x * kUnitsPerBlock;
   const int b0 = blockIdx.y * kStepRows;
 
   if (a.gather) {
-    // next-input token of each row: the forced trajectory, else the argmax over the previous step's per-tile partials
-    // (generator.py:73: first maximal index; tiles are in vocabulary order, so ties go to the smaller index)
-    for (int r = w * 8; r < w * 8 + 8; ++r) {
-      const int b = b0 + r;
+    // next-input token of each row: the forced trajectory, else the first maximal index of the previous step's logits
+    // (generator.py:73), left by vocab_step as a 64-bit atomicMax key per row
+    if (tid < kStepRows) {
+      const int b = b0 + tid;
       int id = 0;
       if (b < a.B) {
         const bool forced = a.force_ids && (!a.force_len || a.tprev < a.force_len[b]);
-        if (forced) {
-          id = (int)a.force_ids[(long)b * a.force_stride + a.tprev];
-        } else if (a.part_m) {
-          float bm = -INFINITY;
-          int bi = 0x7fffffff;
-          for (int j = lane; j < a.nblk; j += 64) {
-            const float m = a.part_m[(long)b * a.nblk + j];
-            const int i = a.part_i[(long)b * a.nblk + j];
-            if (m > bm || (m == bm && i < bi)) { bm = m; bi = i; }
-          }
-          wave_argmax(bm, bi);
-          id = bi;
-        }
+        if (forced) id = (int)a.force_ids[(long)b * a.force_stride + a.tprev];
+        else if (a.rowkey) id = row_key_index(a.rowkey[b]);
         id = id < 0 ? 0 : (id >= a.V ? a.V - 1 : id);
       }
-      if (lane == 0) ids_s[r] = id;
+      ids_s[tid] = id;
     }
     __syncthreads();
   }
@@ -143,94 +157,121 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmStepArgs a) {
   const int ju = j0 + (lr & 3);                       // B-operand row lr = gate (lr >> 2), unit (lr & 3)
   const bool jok = ju < a.H;
   const TA* wrow = (const TA*)a.wcat + (long)((lr >> 2) * a.H + (jok ? ju : 0)) * a.ldx;
-  const TA* arow[4];
-  const float* erow[4];
-  bool aok[4];
+
+  // operands of the pointwise stage (threads 0..255: row tid >> 2, unit tid & 3): requested now, consumed after the products
+  const int pb = b0 + (tid >> 2), pj = j0 + (tid & 3);
+  const bool pok = tid < kStepRows * kUnitsPerBlock && pb < a.B && pj < a.H;
+  float pbias[4] = {0.f, 0.f, 0.f, 0.f}, pc = 0.f;
+  if (pok) {
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int b = b0 + mt * 16 + lr;
-    aok[mt] = b < a.B;
-    arow[mt] = xh + (long)(aok[mt] ? b : 0) * a.ldx;
-    erow[mt] = a.gather ? a.embed + (long)ids_s[mt * 16 + lr] * a.din : nullptr;
+    for (int g = 0; g < 4; ++g) pbias[g] = a.bsum[g * a.H + pj];
+    pc = a.c_prev[(long)pb * a.H + pj];
   }
 
   f32x4 acc[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int nks = (int)((a.ldx + 31) >> 5);
-  for (int ks0 = w * KPI; ks0 < nks; ks0 += 8 * KPI) {
-    Frag<TA> fa[KPI][4], fb[KPI];
+  const int ldx = (int)a.ldx;
+  for (int kc0 = 0; kc0 < ldx; kc0 += KC) {
+    const int kc = min(KC, ldx - kc0);
+    if (kc0) __syncthreads();                          // every wave has read the previous chunk
+    // ---- this wave's weight fragments of the chunk (k-steps w, w+8, ...: at most 4 for KC <= 1024), straight from L2
+    Frag<TA> fb[4];
 #pragma unroll
-    for (int i = 0; i < KPI; ++i) {
-      const int k = (ks0 + i) * 32 + lg * 8;
-      const bool kok = k < a.ldx;                      // ldx % 8 == 0: a fragment is wholly inside or outside
+    for (int i = 0; i < 4; ++i) {
+      const int kl = (w + 8 * i) * 32 + lg * 8;
       fb[i] = zero_frag<TA>();
-      if (kok && jok) fb[i] = load_frag<TA>(wrow + k);
+      if (kl < kc && jok && !(a.dbg & 1)) fb[i] = load_frag<TA>(wrow + kc0 + kl);
+    }
+    // ---- stage the activation chunk [64, kc]: 8 independent 16-byte pieces per thread in flight, then the LDS writes
+    const int cpr = kc / VE;                           // 16-byte pieces per row (kc % 8 == 0)
+    const int total = kStepRows * cpr;
+    for (int c0 = 0; c0 < total; c0 += 8 * 512) {
+      u32x4 v[8];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        fa[i][mt] = zero_frag<TA>();
-        if (kok && aok[mt]) {
-          if (a.gather && k < a.din) fa[i][mt] = frag_from_f32<TA>(erow[mt] + k);      // din % 8 == 0: never straddles x | h
-          else fa[i][mt] = load_frag<TA>(arow[mt] + k);
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i * 512 + tid;
+        const int row = c / cpr, cc = c - row * cpr;
+        const int k = kc0 + cc * VE;
+        v[i] = (u32x4){0u, 0u, 0u, 0u};
+        if (c < total && b0 + row < a.B && !(a.dbg & 2)) {
+          if (a.gather && k < a.din) v[i] = chunk_from_f32<TA>(a.embed + (long)ids_s[row] * a.din + k);   // din % 8 == 0: never straddles x | h
+          else v[i] = *(gptr_u4)(xh + (long)(b0 + row) * a.ldx + k);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i * 512 + tid;
+        const int row = c / cpr, cc = c - row * cpr;
+        if (c < total) *(u32x4*)(sA + row * hs + cc * 16) = v[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kl = (w + 8 * i) * 32 + lg * 8;
+      if ((w + 8 * i) * 32 < kc) {                       // wave-uniform
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          Frag<TA> fa = zero_frag<TA>();
+          if (kl < kc) fa = lds_frag<TA>(sA + (mt * 16 + lr) * hs + kl * SZ);
+          mma<TA>(acc[mt], fa, fb[i]);
         }
       }
     }
-#pragma unroll
-    for (int i = 0; i < KPI; ++i)
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) mma<TA>(acc[mt], fa[i][mt], fb[i]);
   }
+  __syncthreads();                                       // the staging area becomes the reduction buffer
+  float (*red)[kStepRows][17] = (float (*)[kStepRows][17])ls_smem;
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[w][mt * 16 + lg * 4 + r][lr] = acc[mt][r];
   __syncthreads();
 
-  if (tid < kStepRows * kUnitsPerBlock) {
+  if (pok) {
     const int rb = tid >> 2, u = tid & 3;
-    const int b = b0 + rb, j = j0 + u;
-    if (b < a.B && j < a.H) {
-      float g4[4];
+    const int b = pb, j = pj;
+    float g4[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float s = a.bsum[g * a.H + j];
+    for (int g = 0; g < 4; ++g) {
+      float s = pbias[g];
 #pragma unroll
-        for (int ww = 0; ww < 8; ++ww) s += red[ww][rb][g * 4 + u];
-        g4[g] = s;
-      }
-      const float i_ = sigmoidf_(g4[0]), f_ = sigmoidf_(g4[1]), g_ = tanhf(g4[2]), o_ = sigmoidf_(g4[3]);
-      const long bh = (long)b * a.H + j;
-      const float c = f_ * a.c_prev[bh] + i_ * g_;
-      const float h = o_ * tanhf(c);
-      if (a.gates) {
-        float* go = a.gates + (long)b * 4 * a.H + j;
-        go[0] = i_; go[a.H] = f_; go[2 * a.H] = g_; go[3 * a.H] = o_;
-      }
-      a.c_new[bh] = c;
-      const TA hv = from_f32<TA>(h);
-      ((TA*)a.xh_next)[(long)b * a.ldx + a.din + j] = hv;
-      if (a.h_up) ((TA*)a.h_up)[(long)b * a.ld_up + j] = hv;
-      if (a.h_out) ((TA*)a.h_out)[(long)b * a.ld_out + j] = hv;
+      for (int ww = 0; ww < 8; ++ww) s += red[ww][rb][g * 4 + u];
+      g4[g] = s;
     }
+    const float i_ = sigmoidf_(g4[0]), f_ = sigmoidf_(g4[1]), g_ = tanhf(g4[2]), o_ = sigmoidf_(g4[3]);
+    const long bh = (long)b * a.H + j;
+    const float c = f_ * pc + i_ * g_;
+    const float h = o_ * tanhf(c);
+    if (a.gates) {
+      float* go = a.gates + (long)b * 4 * a.H + j;
+      go[0] = i_; go[a.H] = f_; go[2 * a.H] = g_; go[3 * a.H] = o_;
+    }
+    a.c_new[bh] = c;
+    const TA hv = from_f32<TA>(h);
+    ((TA*)a.xh_next)[(long)b * a.ldx + a.din + j] = hv;
+    if (a.h_up) ((TA*)a.h_up)[(long)b * a.ld_up + j] = hv;
+    if (a.h_out) ((TA*)a.h_out)[(long)b * a.ld_out + j] = hv;
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // vocab_step: logits^T tile [64 vocabulary entries x 64 batch rows] = W_out[v0:v0+64, :] . h_t^T on MFMA (generator.py:68),
 // then y = (o + b_out + gumbel(u)) * T (generator.py:69, 84-96), the tile's softmax partials and e = exp(y - tile max).
-// The A operand (weights) is this block's own L2-resident slice, loaded straight into fragments; the B operand (h_t, shared by
-// the four vocabulary sub-tiles) is staged once through LDS.  Waves = 4 vocabulary sub-tiles x 2 K halves; the halves trade
-// two batch sub-tiles each, so that all eight waves share the transcendental-heavy epilogue.
-// In the C tile a lane holds 4 CONSECUTIVE vocabulary entries of one batch row: one Philox4x32 call (or one 16-byte load of
-// explicit uniforms) and one vector store of e per lane and batch sub-tile.
+// Both operand tiles (this block's own L2-resident weight slice and h_t) reach LDS in K chunks of KC by coalesced 16-byte loads;
+// waves = 4 vocabulary sub-tiles x 2 K halves of a chunk; the halves trade two batch sub-tiles each, so that all eight waves
+// share the transcendental-heavy epilogue.  In the C tile a lane holds 4 CONSECUTIVE vocabulary entries of one batch row: one
+// Philox4x32 call (or one 16-byte load of explicit uniforms) and one vector store of e per lane and batch sub-tile.
 template <typename TA, bool FAST>
-__global__ __launch_bounds__(512) void vocab_step_kernel(const VocabStepArgs a) {
+__global__ __launch_bounds__(512) void vocab_step_kernel(const VocabStepArgs a, const int KC) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vs_smem[];
-  constexpr int SZ = sizeof(TA);
+  constexpr int SZ = sizeof(TA), VE = 16 / SZ;
   const int H = a.H, V = a.V;
-  const int hs = H * SZ + 16;                              // LDS row stride of the h tile: 16-B skew against bank conflicts
-  unsigned char* sH = vs_smem;                             // [64][hs]
-  f32x4* sX = (f32x4*)(vs_smem + kStepRows * hs);          // [8 waves][2 tiles][64 lanes]
+  const int hs = KC * SZ + 16;                             // LDS row stride of both tiles: 16-B skew against bank conflicts
+  unsigned char* sW = vs_smem;                             // [64 vocabulary rows][hs]
+  unsigned char* sH = vs_smem + kStepRows * hs;            // [64 batch rows][hs]
+  // after the products the staging area is reused: exchange buffer + reduction scratch
+  f32x4* sX = (f32x4*)vs_smem;                             // [8 waves][2 tiles][64 lanes]
   float* red_m = (float*)(sX + 8 * 2 * 64);                // [4][64] each
   float* red_s = red_m + 4 * kStepRows;
   float* red_y = red_s + 4 * kStepRows;
@@ -241,54 +282,72 @@ __global__ __launch_bounds__(512) void vocab_step_kernel(const VocabStepArgs a) 
   const int mt = w >> 1, kh = w & 1;
   const int v0 = blockIdx.x * kVocabTile, b0 = blockIdx.y * kStepRows;
 
-  // ---- this wave's weight fragments: vocabulary row v0 + 16 mt + lr, k-steps kh, kh+2, ... (up to 8 per chunk)
-  const int vrow = v0 + mt * 16 + lr;
-  const bool vok = vrow < V;
-  const TA* wrow = (const TA*)a.wout + (long)(vok ? vrow : 0) * H;
-  const int nks = (H + 31) >> 5;
-  Frag<TA> fa[8];
-  auto load_a = [&](int c) {
+  // ---- epilogue operands that depend on nothing computed here: requested now
+  const int vq = v0 + mt * 16 + lg * 4;
+  const bool qok = vq < V;                                 // V % 4 == 0: a quad is wholly inside or outside
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (qok) bias4 = *(gptr_f4)(a.bias + vq);
+  f32x4 u4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (a.u && !a.pretrain && qok) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int k = (kh + 2 * (c * 8 + i)) * 32 + lg * 8;
-      fa[i] = zero_frag<TA>();
-      if (vok && k < H) fa[i] = load_frag<TA>(wrow + k);
-    }
-  };
-  load_a(0);
-
-  // ---- stage h_t [64, H] (rows past B: zero)
-  {
-    const int cpr = H * SZ / 16;
-    const unsigned char* hb = (const unsigned char*)a.h;
-    for (int c = tid; c < kStepRows * cpr; c += 512) {
-      const int row = c / cpr, cc = c - row * cpr;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (b0 + row < a.B) v = *(gptr_u4)(hb + ((long)(b0 + row) * a.ldh) * SZ + cc * 16);
-      *(u32x4*)(sH + row * hs + cc * 16) = v;
+    for (int i = 0; i < 2; ++i) {
+      const int b = b0 + (2 * kh + i) * 16 + lr;
+      if (b < a.B) u4[i] = *(gptr_f4)(a.u + (long)b * V + vq);
     }
   }
-  __syncthreads();
 
   f32x4 acc[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int nhalf = (nks - kh + 1) >> 1;                   // k-steps of this K half
-  for (int c = 0; c * 8 < nhalf; ++c) {
-    if (c) load_a(c);
+  const TA* Wg = (const TA*)a.wout;
+  const TA* Hg = (const TA*)a.h;
+  for (int kc0 = 0; kc0 < H; kc0 += KC) {
+    const int kc = min(KC, H - kc0);
+    if (kc0) __syncthreads();
+    // ---- stage W_out[v0:v0+64, kc0:kc0+kc] and h_t[b0:b0+64, kc0:kc0+kc]: up to 8 + 8 pieces per thread in flight per pass
+    const int cpr = kc / VE;
+    const int total = kStepRows * cpr;
+    for (int c0 = 0; c0 < total; c0 += 8 * 512) {
+      u32x4 vw[8], vh[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int k = (kh + 2 * (c * 8 + i)) * 32 + lg * 8;
-      if (c * 8 + i < nhalf) {                             // wave-uniform
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i * 512 + tid;
+        const int row = c / cpr, cc = c - row * cpr;
+        vw[i] = (u32x4){0u, 0u, 0u, 0u};
+        vh[i] = (u32x4){0u, 0u, 0u, 0u};
+        if (c < total) {
+          if (v0 + row < V && !(a.dbg & 1)) vw[i] = *(gptr_u4)(Wg + (long)(v0 + row) * H + kc0 + cc * VE);
+          if (b0 + row < a.B && !(a.dbg & 4)) vh[i] = *(gptr_u4)(Hg + (long)(b0 + row) * a.ldh + kc0 + cc * VE);
+        }
+      }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          Frag<TA> fb = zero_frag<TA>();
-          if (k < H) fb = lds_frag<TA>(sH + (nt * 16 + lr) * hs + k * SZ);
-          mma<TA>(acc[nt], fa[i], fb);
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i * 512 + tid;
+        const int row = c / cpr, cc = c - row * cpr;
+        if (c < total) {
+          *(u32x4*)(sW + row * hs + cc * 16) = vw[i];
+          *(u32x4*)(sH + row * hs + cc * 16) = vh[i];
         }
       }
     }
+    __syncthreads();
+    // ---- products: the chunk's k-steps split in two contiguous halves
+    const int nks = (kc + 31) >> 5;
+    const int half0 = (nks + 1) >> 1;
+    const int ks_lo = kh ? half0 : 0, ks_hi = kh ? nks : half0;
+    for (int ks = ks_lo; ks < ks_hi && !(a.dbg & 2); ++ks) {
+      const int kl = ks * 32 + lg * 8;
+      Frag<TA> fa = zero_frag<TA>();
+      if (kl < kc) fa = lds_frag<TA>(sW + (mt * 16 + lr) * hs + kl * SZ);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        Frag<TA> fb = zero_frag<TA>();
+        if (kl < kc) fb = lds_frag<TA>(sH + (nt * 16 + lr) * hs + kl * SZ);
+        mma<TA>(acc[nt], fa, fb);
+      }
+    }
   }
+  __syncthreads();                                         // staging area -> exchange / reduction scratch
 
   // ---- K halves: wave (mt, kh) keeps batch sub-tiles 2kh, 2kh+1 and receives the partner's partial sums for them
   // (element-wise selects: a select between accumulator ARRAY elements would become a dynamic index and move them to scratch)
@@ -311,10 +370,6 @@ __global__ __launch_bounds__(512) void vocab_step_kernel(const VocabStepArgs a) 
   }
 
   // ---- epilogue: lane = batch row b0 + 16 nt + lr, vocabulary entries vq .. vq+3
-  const int vq = v0 + mt * 16 + lg * 4;
-  const bool qok = vq < V;                                 // V % 4 == 0: a quad is wholly inside or outside
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (qok) bias4 = *(gptr_f4)(a.bias + vq);
   const float bia[4] = {bias4[0], bias4[1], bias4[2], bias4[3]};
   const float eps = 1e-10f;                                // generator.py:84
   float y[2][4];
@@ -331,8 +386,7 @@ __global__ __launch_bounds__(512) void vocab_step_kernel(const VocabStepArgs a) 
       float uu[4] = {0.f, 0.f, 0.f, 0.f};
       if (!a.pretrain) {
         if (a.u) {
-          const f32x4 uv = *(gptr_f4)(a.u + (long)brow[i] * V + vq);
-          uu[0] = uv[0]; uu[1] = uv[1]; uu[2] = uv[2]; uu[3] = uv[3];
+          uu[0] = u4[i][0]; uu[1] = u4[i][1]; uu[2] = u4[i][2]; uu[3] = u4[i][3];
         } else {
           uint32_t r0, r1, r2, r3;
           Philox::gen4(a.seed, a.rng_stream, (uint64_t)brow[i] * (uint64_t)(V >> 2) + (uint64_t)(vq >> 2), r0, r1, r2, r3);
@@ -403,7 +457,7 @@ __global__ __launch_bounds__(512) void vocab_step_kernel(const VocabStepArgs a) 
     const long o = (long)(b0 + tid) * a.nblk + blockIdx.x;
     a.part_m[o] = m;
     a.part_s[o] = s;
-    a.part_i[o] = bi;
+    atomicMax(a.rowkey + b0 + tid, row_key(m, bi));
   }
 }
 
@@ -414,27 +468,12 @@ __global__ __launch_bounds__(512) void vocab_step_kernel(const VocabStepArgs a) 
 template <typename TA>
 __global__ __launch_bounds__(256) void sample_finish_kernel(const SampleFinishArgs a) {
   __shared__ float red[16];
-  __shared__ float red_v[4];
-  __shared__ int red_i[4];
   __shared__ float scale_s[1024];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x;
   const int t = blockIdx.x / a.B, b = blockIdx.x % a.B;
   const long po = ((long)t * a.B + b) * a.nblk;
   const float* pm = a.part_m + po;
-  float bm = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int j = tid; j < a.nblk; j += 256) {
-    const float m = pm[j];
-    const int i = a.part_i[po + j];
-    if (m > bm || (m == bm && i < bi)) { bm = m; bi = i; }
-  }
-  wave_argmax(bm, bi);
-  if (lane == 0) { red_v[w] = bm; red_i[w] = bi; }
-  __syncthreads();
-  bm = red_v[0]; bi = red_i[0];
-  for (int q = 1; q < 4; ++q)
-    if (red_v[q] > bm || (red_v[q] == bm && red_i[q] < bi)) { bm = red_v[q]; bi = red_i[q]; }
-  int id = bi;
+  int id = row_key_index(a.rowkey[(long)t * a.B + b]);
   if (a.force_ids && (!a.force_len || t < a.force_len[b])) id = (int)a.force_ids[(long)b * a.L + t];
   id = id < 0 ? 0 : (id >= a.V ? a.V - 1 : id);
   if (tid == 0) a.ids[(long)b * a.L + t] = id;
@@ -443,6 +482,9 @@ __global__ __launch_bounds__(256) void sample_finish_kernel(const SampleFinishAr
     for (int e = tid; e < a.E; e += 256) dst[e] = from_f32<TA>(a.embed[(long)id * a.E + e]);
   }
   if (!a.out || a.pretrain) return;
+  float bm = -INFINITY;
+  for (int j = tid; j < a.nblk; j += 256) bm = fmaxf(bm, pm[j]);
+  bm = block_max(bm, red);
   float s = 0.f;
   for (int j = tid; j < a.nblk; j += 256) s += a.part_s[po + j] * expf(pm[j] - bm);
   s = block_sum(s, red);
@@ -462,19 +504,89 @@ __global__ __launch_bounds__(256) void sample_finish_kernel(const SampleFinishAr
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// lstm_bwd_step: see decoder_step.h.  C[b, j] = sum over up to two K segments of A_seg[b, k] * W_seg[j, k].
+template <typename TA, int KPI>
+__global__ __launch_bounds__(512) void lstm_bwd_step_kernel(const LstmBwdStepArgs a) {
+  __shared__ float red[8][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+  const int K = 4 * a.H;
+  const bool bok = b0 + lr < a.B, jok = j0 + lr < a.H;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int nks = (K + 31) >> 5;
+#pragma unroll
+  for (int seg = 0; seg < 2; ++seg) {
+    const TA* A = (const TA*)(seg ? a.dg_up : a.dg_next);
+    const TA* W = (const TA*)(seg ? a.w_up : a.w_rec);
+    if (!A) continue;                                    // block-uniform
+    const TA* arow = A + (long)(bok ? b0 + lr : 0) * K;
+    const TA* wrow = W + (long)(jok ? j0 + lr : 0) * K;
+    for (int ks0 = w * KPI; ks0 < nks; ks0 += 8 * KPI) {
+      Frag<TA> fa[KPI], fb[KPI];
+#pragma unroll
+      for (int i = 0; i < KPI; ++i) {
+        const int k = (ks0 + i) * 32 + lg * 8;
+        fa[i] = zero_frag<TA>();
+        fb[i] = zero_frag<TA>();
+        if (k < K && bok) fa[i] = load_frag<TA>(arow + k);
+        if (k < K && jok) fb[i] = load_frag<TA>(wrow + k);
+      }
+#pragma unroll
+      for (int i = 0; i < KPI; ++i) mma<TA>(acc, fa[i], fb[i]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[w][lg * 4 + r][lr] = acc[r];
+  __syncthreads();
+  if (tid < 256) {
+    const int rb = tid >> 4, u = tid & 15;
+    const int b = b0 + rb, j = j0 + u;
+    if (b < a.B && j < a.H) {
+      float dh = a.dh_above ? a.dh_above[(long)b * a.ld_above + j] : 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) dh += red[ww][rb][u];
+      const float* g = a.gates + (long)b * K;
+      const float i_ = g[j], f_ = g[a.H + j], g_ = g[2 * a.H + j], o_ = g[3 * a.H + j];
+      const long bh = (long)b * a.H + j;
+      const float tc = tanhf(a.c_cur[bh]);
+      const float dc = a.dc_state[bh] + dh * o_ * (1.f - tc * tc);
+      TA* dg = (TA*)a.dgates + (long)b * K;
+      dg[j] = from_f32<TA>(dc * g_ * i_ * (1.f - i_));
+      dg[a.H + j] = from_f32<TA>(dc * a.c_prev[bh] * f_ * (1.f - f_));
+      dg[2 * a.H + j] = from_f32<TA>(dc * i_ * (1.f - g_ * g_));
+      dg[3 * a.H + j] = from_f32<TA>(dh * tc * o_ * (1.f - o_));
+      a.dc_state[bh] = dc * f_;
+    }
+  }
+}
+
+// dynamic LDS beyond 64 KB must be granted per kernel; `granted` = what the caller's kernel already has (one static per kernel)
 template <typename K>
-int allow_lds(K kernel, size_t bytes) {
-  if (bytes <= 64 * 1024) return GIC_OK;
+int allow_lds(K kernel, size_t bytes, size_t& granted) {
+  if (bytes <= granted) return GIC_OK;
   if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
     (void)hipGetLastError();
-    set_last_error("vocab_step: cannot reserve %zu bytes of LDS", bytes);
+    set_last_error("decoder step kernel: cannot reserve %zu bytes of LDS", bytes);
     return GIC_ERR_LAUNCH;
   }
+  granted = bytes;
   return GIC_OK;
 }
 
+// K chunk (elements) staged per pass: 1 KiB of a row in vocab_step (two tiles), 2 KiB in lstm_step (one tile); multiples of 32
+int vocab_chunk(int dtype, int H) { const int cap = 1024 / dtype_size(dtype); const int h = (H + 31) & ~31; return h < cap ? h : cap; }
+int lstm_chunk(int dtype, int ldx) { const int cap = 2048 / dtype_size(dtype); const int k = (ldx + 31) & ~31; return k < cap ? k : cap; }
 size_t vocab_lds_bytes(int dtype, int H) {
-  return (size_t)kStepRows * ((size_t)H * dtype_size(dtype) + 16) + 8 * 2 * 64 * 16 + 4 * 4 * kStepRows * 4;
+  const size_t stage = (size_t)2 * kStepRows * ((size_t)vocab_chunk(dtype, H) * dtype_size(dtype) + 16);
+  const size_t scratch = 8 * 2 * 64 * 16 + 4 * 4 * kStepRows * 4;
+  return stage > scratch ? stage : scratch;
+}
+size_t lstm_lds_bytes(int dtype, int ldx) {
+  const size_t stage = (size_t)kStepRows * ((size_t)lstm_chunk(dtype, ldx) * dtype_size(dtype) + 16);
+  const size_t red = (size_t)8 * kStepRows * 17 * 4;
+  return stage > red ? stage : red;
 }
 
 }  // namespace
@@ -483,45 +595,72 @@ bool decoder_step_supported(int dtype, int V, int E, int H, int NL) {
   static const bool off = getenv("GIC_NO_FUSED_ROLLOUT") != nullptr;
   if (off) return false;
   if (V < 4 || V % 4 || E % 8 || H % 8 || NL < 1) return false;
-  if ((V + kVocabTile - 1) / kVocabTile > 1024) return false;          // sample_finish's scale table
-  return vocab_lds_bytes(dtype, H) <= 160 * 1024 - 1024;
+  (void)dtype;
+  return (V + kVocabTile - 1) / kVocabTile <= 1024;                    // sample_finish's scale table
 }
 
 size_t decoder_step_part_floats(int B, int L, int V) {
-  return (size_t)3 * L * B * ((V + kVocabTile - 1) / kVocabTile);
+  return (size_t)2 * L * B * ((V + kVocabTile - 1) / kVocabTile) + (size_t)2 * L * B + 2;     // + the 64-bit row keys (8-byte aligned)
 }
+
+static int g_step_dbg = 0;
+void decoder_step_debug(int v) { g_step_dbg = v; }
 
 int lstm_step(const LstmStepArgs& a, int dtype, hipStream_t stream) {
   GIC_CHECK_ARG(a.xh_t && a.xh_next && a.wcat && a.bsum && a.c_prev && a.c_new, "lstm_step: null buffer");
   GIC_CHECK_ARG(a.B > 0 && a.H > 0 && a.din > 0 && a.ldx == (long)a.din + a.H && a.ldx % 8 == 0 && a.din % 8 == 0, "lstm_step: bad dims");
-  GIC_CHECK_ARG(!a.gather || (a.embed && a.V > 0 && (a.part_m || a.force_ids) && (!a.part_m || (a.part_i && a.nblk > 0))), "lstm_step: bad gather arguments");
+  GIC_CHECK_ARG(!a.gather || (a.embed && a.V > 0 && (a.rowkey || a.force_ids)), "lstm_step: bad gather arguments");
   const dim3 grid((unsigned)cdiv(a.H, kUnitsPerBlock), (unsigned)cdiv(a.B, kStepRows));
-  if (dtype == DT_F32) hipLaunchKernelGGL((lstm_step_kernel<float, 2>), grid, dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL((lstm_step_kernel<bf16_t, 4>), grid, dim3(512), 0, stream, a);
+  LstmStepArgs b = a;
+  b.dbg = g_step_dbg;
+  const int KC = lstm_chunk(dtype, (int)a.ldx);
+  const size_t lds = lstm_lds_bytes(dtype, (int)a.ldx);
+  static size_t granted_f32 = 64 * 1024, granted_bf16 = 64 * 1024;
+  if (dtype == DT_F32) {
+    GIC_PROPAGATE(allow_lds(lstm_step_kernel<float>, lds, granted_f32));
+    hipLaunchKernelGGL((lstm_step_kernel<float>), grid, dim3(512), lds, stream, b, KC);
+  } else {
+    GIC_PROPAGATE(allow_lds(lstm_step_kernel<bf16_t>, lds, granted_bf16));
+    hipLaunchKernelGGL((lstm_step_kernel<bf16_t>), grid, dim3(512), lds, stream, b, KC);
+  }
   GIC_CHECK_LAUNCH("lstm_step");
   return GIC_OK;
 }
 
-int vocab_step(const VocabStepArgs& a, int dtype, hipStream_t stream) {
-  GIC_CHECK_ARG(a.h && a.wout && a.bias && a.part_m && a.part_s && a.part_i, "vocab_step: null buffer");
+int lstm_bwd_step(const LstmBwdStepArgs& a, int dtype, hipStream_t stream) {
+  GIC_CHECK_ARG(a.gates && a.c_prev && a.c_cur && a.dc_state && a.dgates && a.B > 0 && a.H > 0 && a.H % 2 == 0, "lstm_bwd_step: bad arguments");
+  GIC_CHECK_ARG((!a.dg_next || a.w_rec) && (!a.dg_up || a.w_up), "lstm_bwd_step: a gradient operand without its weights");
+  const dim3 grid((unsigned)cdiv(a.H, 16), (unsigned)cdiv(a.B, 16));
+  if (dtype == DT_F32) hipLaunchKernelGGL((lstm_bwd_step_kernel<float, 4>), grid, dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((lstm_bwd_step_kernel<bf16_t, 8>), grid, dim3(512), 0, stream, a);
+  GIC_CHECK_LAUNCH("lstm_bwd_step");
+  return GIC_OK;
+}
+
+int vocab_step(const VocabStepArgs& a0, int dtype, hipStream_t stream) {
+  VocabStepArgs a = a0;
+  a.dbg = g_step_dbg;
+  GIC_CHECK_ARG(a.h && a.wout && a.bias && a.part_m && a.part_s && a.rowkey, "vocab_step: null buffer");
   GIC_CHECK_ARG(a.B > 0 && a.V >= 4 && a.V % 4 == 0 && a.H % 8 == 0 && a.ldh % 8 == 0, "vocab_step: bad dims");
   GIC_CHECK_ARG(a.nblk == cdiv(a.V, kVocabTile), "vocab_step: nblk must be ceil(V / %d)", kVocabTile);
   GIC_CHECK_ARG(!a.out || a.out_stride % 4 == 0, "vocab_step: out row stride must be a multiple of 4");
   const size_t lds = vocab_lds_bytes(dtype, a.H);
+  const int KC = vocab_chunk(dtype, a.H);
   const dim3 grid((unsigned)a.nblk, (unsigned)cdiv(a.B, kStepRows));
+  static size_t granted_f32 = 64 * 1024, granted_bf16 = 64 * 1024;
   if (dtype == DT_F32) {
-    GIC_PROPAGATE(allow_lds(vocab_step_kernel<float, false>, lds));
-    hipLaunchKernelGGL((vocab_step_kernel<float, false>), grid, dim3(512), lds, stream, a);
+    GIC_PROPAGATE(allow_lds(vocab_step_kernel<float, false>, lds, granted_f32));
+    hipLaunchKernelGGL((vocab_step_kernel<float, false>), grid, dim3(512), lds, stream, a, KC);
   } else {
-    GIC_PROPAGATE(allow_lds(vocab_step_kernel<bf16_t, true>, lds));
-    hipLaunchKernelGGL((vocab_step_kernel<bf16_t, true>), grid, dim3(512), lds, stream, a);
+    GIC_PROPAGATE(allow_lds(vocab_step_kernel<bf16_t, true>, lds, granted_bf16));
+    hipLaunchKernelGGL((vocab_step_kernel<bf16_t, true>), grid, dim3(512), lds, stream, a, KC);
   }
   GIC_CHECK_LAUNCH("vocab_step");
   return GIC_OK;
 }
 
 int sample_finish(const SampleFinishArgs& a, int dtype, hipStream_t stream) {
-  GIC_CHECK_ARG(a.part_m && a.part_s && a.part_i && a.ids && a.nblk > 0 && a.nblk <= 1024, "sample_finish: bad partials");
+  GIC_CHECK_ARG(a.part_m && a.part_s && a.rowkey && a.ids && a.nblk > 0 && a.nblk <= 1024, "sample_finish: bad partials");
   GIC_CHECK_ARG(a.B > 0 && a.L > 0 && a.V % 4 == 0, "sample_finish: bad dims");
   GIC_CHECK_ARG(!a.xh0 || a.embed, "sample_finish: the x rows need the embedding table");
   const dim3 grid((unsigned)((long)a.B * a.L));

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(1024) void gan_losses_kernel(int type, const float*
 template <typename TA>
 __global__ __launch_bounds__(256) void xent_rows_kernel(const TA* __restrict__ logits, long rows, int V,
                                                          const int64_t* __restrict__ targets, float* __restrict__ row_loss,
-                                                         TA* __restrict__ dlogits) {
+                                                         TA* __restrict__ dlogits, const float* __restrict__ row_weight) {
   __shared__ float red[16];
   const long row = blockIdx.x;
   const TA* x = logits + row * V;
@@ -93,9 +93,10 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const TA* __restrict__ l
   const bool bad = tgt < 0 || tgt >= V;
   tgt = bad ? 0 : tgt;
   const float lse = mx + logf(s);
-  if (threadIdx.x == 0) row_loss[row] = bad ? NAN : lse - to_f32<TA>(x[tgt]);
+  const float wgt = row_weight ? row_weight[row] : 1.f;       // REINFORCE: the row's reward (policy-gradient loss); 1 for plain NLL
+  if (threadIdx.x == 0) row_loss[row] = bad ? NAN : wgt * (lse - to_f32<TA>(x[tgt]));
   if (dlogits) {
-    const float inv_rows = 1.f / (float)rows;
+    const float inv_rows = wgt / (float)rows;
     for (int v = threadIdx.x; v < V; v += 256) {
       const float p = expf(to_f32<TA>(x[v]) - mx) / s;
       dlogits[row * V + v] = from_f32<TA>((p - (v == tgt ? 1.f : 0.f)) * inv_rows);
@@ -108,6 +109,26 @@ __global__ __launch_bounds__(1024) void mean_kernel(const float* __restrict__ x,
   for (long i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
   s = block_sum(s, red);
   if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+
+// ---- Monte-Carlo roll-out rewards (SeqGAN): reward[b, t] = mean over the N roll-outs of prefix length t+1 (and the R representation
+// logits of each) of sigmoid(D logit); the last position is scored on the complete caption itself.  One block per (b, t).
+__global__ __launch_bounds__(256) void rollout_rewards_kernel(const float* __restrict__ mc_logits, const float* __restrict__ full_logits,
+                                                               float* __restrict__ rewards, int B, int L, int N, int R) {
+  __shared__ float red[16];
+  const int b = blockIdx.x / L, t = blockIdx.x % L;
+  float s = 0.f;
+  if (t + 1 < L) {
+    for (int i = threadIdx.x; i < N * R; i += 256) {
+      const int n = i / R, r = i % R;
+      s += 1.f / (1.f + expf(-mc_logits[(((long)t * N + n) * B + b) * R + r]));
+    }
+    s = block_sum(s, red) / (float)(N * R);
+  } else {
+    for (int r = threadIdx.x; r < R; r += 256) s += 1.f / (1.f + expf(-full_logits[(long)b * R + r]));
+    s = block_sum(s, red) / (float)R;
+  }
+  if (threadIdx.x == 0) rewards[(long)b * L + t] = s;
 }
 
 // ---- clip + Adam -----------------------------------------------------------------------------
@@ -173,19 +194,27 @@ int gic_gan_losses(int loss_type, const float* d_real, const float* d_fake, cons
 }
 
 // `loss`: device f32[1 + rows]: loss[0] = mean, loss[1..] = per-row scratch.
-int gic_xent(const void* logits, int dtype, int64_t rows, int32_t V, const int64_t* targets, float* loss, void* d_logits, void* stream_) {
+int gic_xent(const void* logits, int dtype, int64_t rows, int32_t V, const int64_t* targets, float* loss, void* d_logits,
+             const float* row_weight, void* stream_) {
   GIC_CHECK_ARG(logits && targets && loss && rows > 0 && V > 0, "xent: bad argument");
   hipStream_t stream = (hipStream_t)stream_;
   if (dtype == DT_F32)
     hipLaunchKernelGGL((xent_rows_kernel<float>), dim3((unsigned)rows), dim3(256), 0, stream, (const float*)logits, (long)rows, V, targets,
-                       loss + 1, (float*)d_logits);
+                       loss + 1, (float*)d_logits, row_weight);
   else if (dtype == DT_BF16)
     hipLaunchKernelGGL((xent_rows_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, stream, (const bf16_t*)logits, (long)rows, V, targets,
-                       loss + 1, (bf16_t*)d_logits);
+                       loss + 1, (bf16_t*)d_logits, row_weight);
   else { set_last_error("xent: bad dtype %d", dtype); return GIC_ERR_UNSUPPORTED; }
   GIC_CHECK_LAUNCH("xent_rows");
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, stream, (const float*)(loss + 1), (long)rows, loss);
   GIC_CHECK_LAUNCH("xent_mean");
+  return GIC_OK;
+}
+
+int gic_rollout_rewards(const float* mc_logits, const float* full_logits, float* rewards, int B, int L, int N, int R, void* stream) {
+  GIC_CHECK_ARG(full_logits && rewards && B > 0 && L > 0 && R > 0 && (L == 1 || (mc_logits && N > 0)), "rollout_rewards: bad argument");
+  hipLaunchKernelGGL(rollout_rewards_kernel, dim3((unsigned)(B * L)), dim3(256), 0, (hipStream_t)stream, mc_logits, full_logits, rewards, B, L, N, R);
+  GIC_CHECK_LAUNCH("rollout_rewards");
   return GIC_OK;
 }
 

@@ -120,15 +120,30 @@ def gan_losses(loss_type: str, d_real, d_fake, g_out, want_grads: bool = True):
     return losses, g
 
 
-def xent(logits: torch.Tensor, targets: torch.Tensor, want_grad: bool = True):
-    """CrossEntropyLoss(mean over all rows). logits [rows,V] (f32/bf16, contiguous). Returns (loss[1], d_logits|None)."""
-    require_gpu(logits, targets)
+def xent(logits: torch.Tensor, targets: torch.Tensor, want_grad: bool = True, row_weight: Optional[torch.Tensor] = None):
+    """CrossEntropyLoss(mean over all rows). logits [rows,V] (f32/bf16, contiguous). Returns (loss[1], d_logits|None).
+    ``row_weight`` f32 [rows]: weighted form (policy-gradient loss, gicap.h)."""
+    require_gpu(logits, targets, row_weight)
     rows, V = logits.shape
     dt = L.F32 if logits.dtype == torch.float32 else L.BF16
     buf = torch.empty(1 + rows, device=logits.device, dtype=torch.float32)
     dl = torch.empty_like(logits) if want_grad else None
-    L.check(L.load().gic_xent(ptr(logits), dt, rows, V, ptr(targets.contiguous()), ptr(buf), ptr(dl), stream_ptr()), "gic_xent")
+    if row_weight is not None:
+        row_weight = row_weight.contiguous().float()
+        if row_weight.numel() != rows:
+            raise ValueError("row_weight must hold one weight per row")
+    L.check(L.load().gic_xent(ptr(logits), dt, rows, V, ptr(targets.contiguous()), ptr(buf), ptr(dl), ptr(row_weight), stream_ptr()),
+            "gic_xent")
     return buf[:1], dl
+
+
+def rollout_rewards(mc_logits: Optional[torch.Tensor], full_logits: torch.Tensor, B: int, Lc: int, N: int, R: int) -> torch.Tensor:
+    """gic_rollout_rewards: f32 [B, L] Monte-Carlo rewards from D's logits on the roll-outs (gicap.h)."""
+    require_gpu(mc_logits, full_logits)
+    out = torch.empty(B, Lc, device=full_logits.device, dtype=torch.float32)
+    L.check(L.load().gic_rollout_rewards(ptr(mc_logits), ptr(full_logits.contiguous()), ptr(out), B, Lc, N, R, stream_ptr()),
+            "gic_rollout_rewards")
+    return out
 
 
 # ------------------------------------------------------------------------------------------ decoder
@@ -186,8 +201,8 @@ class DecoderEngine:
                 "wcat": [torch.empty(4 * self.H, self.ldx(l), device=dev, dtype=self.act) for l in range(self.NL)],
                 "bsum": [torch.empty(4 * self.H, device=dev, dtype=torch.float32) for l in range(self.NL)],
                 "wout": None if self.dt == L.F32 else torch.empty(self.V, self.H, device=dev, dtype=self.act),
-                # bf16 mode: Wcat^T so that the BPTT product d[x|h] = d_gates Wcat runs on k-contiguous operands
-                "wcat_t": None if self.dt == L.F32 else [torch.empty(self.ldx(l), 4 * self.H, device=dev, dtype=self.act) for l in range(self.NL)],
+                # Wcat^T: the k-contiguous weight operand of the BPTT products d[x|h] = d_gates Wcat (fused BPTT step kernel)
+                "wcat_t": [torch.empty(self.ldx(l), 4 * self.H, device=dev, dtype=self.act) for l in range(self.NL)],
             }
         sh = self._shadow
         s = self._shadow_struct(params)
@@ -217,8 +232,12 @@ class DecoderEngine:
             "logits": torch.empty(B, self.V, device=dev, dtype=f32),
             "gpre": torch.empty(B, 4 * self.H, device=dev, dtype=f32),
             # per-tile softmax partials of the fused step kernels ([3][L][B][ceil(V/64)], decoder_step.h)
-            "part": torch.empty(3 * Lc * B * ((self.V + 63) // 64), device=dev, dtype=f32),
+            "part": torch.empty(self.part_floats(B, Lc), device=dev, dtype=f32),
         }
+
+    def part_floats(self, B: int, Lc: int) -> int:
+        """Floats of the fused step kernels' scratch: [2][L][B][ceil(V/64)] tile partials + [L][B] 64-bit argmax keys (gicap.h)."""
+        return 2 * Lc * B * ((self.V + 63) // 64) + 2 * Lc * B + 2
 
     def alloc_rollout_state(self, B: int, Lc: int, dev) -> Dict[str, object]:
         """State of an inference roll-out (``no_state``): recurrent buffers only, nothing saved for a backward pass."""
@@ -227,8 +246,11 @@ class DecoderEngine:
             "xh": [torch.empty(Lc + 1, B, self.ldx(l), device=dev, dtype=self.act) for l in range(self.NL)],
             "gates": [None] * self.NL,
             "c": [torch.empty(Lc + 1, B, self.H, device=dev, dtype=f32) for _ in range(self.NL)],
-            "hout": None, "logits": None, "gpre": None,
-            "part": torch.empty(3 * Lc * B * ((self.V + 63) // 64), device=dev, dtype=f32),
+            "hout": None,
+            # beyond the fused kernels' row limit the roll-out runs as generic products: their scratch
+            "logits": torch.empty(B, self.V, device=dev, dtype=f32) if B > 512 else None,
+            "gpre": torch.empty(B, 4 * self.H, device=dev, dtype=f32) if B > 512 else None,
+            "part": torch.empty(self.part_floats(B, Lc), device=dev, dtype=f32) if B <= 512 else None,
         }
 
     def _state_struct(self, st) -> L.DecoderState:
@@ -346,7 +368,8 @@ class DecoderEngine:
 
     def sample_bwd(self, params, st, out: torch.Tensor, ids: torch.Tensor, d_out: torch.Tensor, temperature: float,
                    pretrain: bool = False, ws=None, grads=None, phases: int = 3) -> List[torch.Tensor]:
-        """phases: 1 = output layer only (w_out / b_out gradients complete), 2 = recurrent part, 3 = both (gicap.h)."""
+        """phases: 1 = output layer only (w_out / b_out gradients complete), 2 = recurrent part, 3 = both; | 4 = also the gradient of
+        the initial states, read back with ``state_grads(ws)`` (gicap.h)."""
         B, Lc = ids.shape
         dev = out.device
         if d_out.dtype != self.act:

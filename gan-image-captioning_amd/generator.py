@@ -116,7 +116,8 @@ class _SampleFn(torch.autograd.Function):
     def backward(ctx, d_out, _d_ids):
         out, ids = ctx.saved_tensors
         ws = ctx.eng.alloc_bwd_ws(ids.shape[0], ids.shape[1], out.device)
-        grads = ctx.eng.sample_bwd(ctx.dparams, ctx.st, out, ids, d_out, ctx.temperature, ctx.pretrain, ws=ws)
+        grads = ctx.eng.sample_bwd(ctx.dparams, ctx.st, out, ids, d_out, ctx.temperature, ctx.pretrain, ws=ws,
+                                   phases=7 if ctx.has_states else 3)
         ctx.st = None
         d_h0 = d_c0 = None
         if ctx.has_states:        # gradients into the initial states: slot 0 of the recurrent input-gradient buffers

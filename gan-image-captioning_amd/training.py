@@ -24,6 +24,7 @@ from tqdm import tqdm
 from . import engine, parallel
 from .discriminator import Discriminator
 from .fused_step import FusedAdvStep
+from .seqgan import SeqGANStep
 from .generator import Generator
 from .optim import FusedClipAdam, ParamArena
 from .tasks import collate_fn
@@ -102,6 +103,9 @@ class GANInstructor:
         self.reducer = parallel.GradReducer(self.dist) if self.dist.world_size > 1 else None
         self.fused = FusedAdvStep(self.gen, self.disc, self.gen_arena, self.disc_arena, args, self.reducer
                                   ).bind_optimizers(self.gen_opt, self.disc_opt)
+        # --adv-mode seqgan: policy gradient + Monte-Carlo roll-outs (no reference counterpart; seqgan.py)
+        self.seqgan = SeqGANStep(self.gen, self.disc, self.gen_arena, self.disc_arena, args, self.reducer
+                                 ).bind_optimizers(self.gen_opt, self.disc_opt)
 
         self.train_dataset, self.dev_dataset = train_dataset, dev_dataset
         nw = int(getattr(args, "num_workers", 4))
@@ -203,6 +207,8 @@ class GANInstructor:
         """One minibatch.  Returns (g_loss, d_loss) as a 2-element device tensor (one host sync to read).
         ``next_images`` (optional): the next batch's images on the device, for the trunk prefetch of the fused step."""
         impl = getattr(self.args, "step_impl", "fused")
+        if getattr(self.args, "adv_mode", "relgan") == "seqgan":
+            return self.seqgan(images, captions, max_caption_len, train)["losses"]
         if impl == "fused":
             return self.fused(images, captions, max_caption_len, train, noise_u, keep_masks, next_images=next_images)["losses"]
         return self._adv_step_autograd(images, captions, max_caption_len, train, noise_u, keep_masks)

@@ -97,7 +97,8 @@ typedef struct gic_decoder_shadow {
   float* bsum[GIC_MAX_LAYERS];           /* [4H] = b_ih + b_hh */
   void* wout;                            /* act [V,H] (may alias params.w_out in f32 mode) */
   void* wcat_t[GIC_MAX_LAYERS];          /* act [Din_k+H, 4H] = Wcat^T, the k-contiguous operand of the BPTT input-gradient
-                                            product; NULL: that product reads Wcat transposed instead */
+                                            product (the fused BPTT step kernel needs it); NULL: that product reads Wcat
+                                            transposed instead, one generic product + one pointwise launch per step */
 } gic_decoder_shadow;
 
 /* Saved-for-backward state + scratch of one sample() call (caller-owned). Din_0=E, Din_k=H. */
@@ -108,8 +109,9 @@ typedef struct gic_decoder_state {
   void* hout;                            /* act [B, L, H] last layer's h, batch-major (vocab GEMM operand) */
   float* logits;                         /* scratch [B, V] */
   float* gpre;                           /* scratch [B, 4H] */
-  float* part;                           /* scratch [3][L][B][ceil(V/64)]: per-tile softmax partials of the fused step kernels
-                                            (max, sum of exp, first maximal index).  NULL selects the unfused launches. */
+  float* part;                           /* scratch of the fused step kernels: [2][L][B][ceil(V/64)] per-tile softmax partials (max, sum of
+                                            exp) + [L][B] 64-bit argmax keys; size from gic_decoder_state_bytes, 8-byte aligned.
+                                            NULL selects the unfused launches. */
 } gic_decoder_state;
 
 typedef struct gic_decoder_bwd_ws {      /* scratch for backward (caller-owned) */
@@ -150,6 +152,9 @@ int gic_decoder_sample_fwd(const gic_decoder_dims* dims, const gic_decoder_param
                            const float* features, const float* noise_u, uint64_t seed, float temperature,
                            int pretrain, void* out, int64_t* ids, const gic_decoder_sample_opts* opts, void* stream);
 
+/* Tools only (tools/rollout_bench.py): phase-ablation mask of the fused step kernels; 0 = normal operation. */
+void gic_debug_decoder_step(int mask);
+
 /* Decoder.forward, the teacher-forced decode (src/generator.py:39-53; forward only: the reference's training never calls it).
  * dims->L = T = caption length + 1 time steps: step 0 is fed `features`, step t > 0 embed(caps[b, t-1]) (caps int64 [B, T-1]).
  * lengths int32 [B] (each 1..T) with pack_padded_sequence semantics: a row past its length keeps its state and contributes a
@@ -170,6 +175,9 @@ int gic_decoder_forward_tf(const gic_decoder_dims* dims, const gic_decoder_param
 #define GIC_DECODER_BWD_OUTPUT 1
 #define GIC_DECODER_BWD_RECURRENT 2
 #define GIC_DECODER_BWD_ALL 3
+/* with GIC_DECODER_BWD_RECURRENT: also the gradient of the initial states (sample(states=...)): d h0 of layer k is left in the h
+ * columns of ws->dxh[k] slot 0, d c0 in ws->dc[k] */
+#define GIC_DECODER_BWD_STATE_GRADS 4
 int gic_decoder_sample_bwd(const gic_decoder_dims* dims, const gic_decoder_params* params,
                            const gic_decoder_shadow* shadow, const gic_decoder_state* state,
                            const gic_decoder_bwd_ws* ws, const void* probs, const int64_t* ids,
@@ -335,9 +343,17 @@ int gic_gan_losses(int loss_type, const float* d_real, const float* d_fake, cons
                    void* stream);
 
 /* CrossEntropyLoss over all rows (training.py:81-83): loss = device f32[1+rows] (loss[0] = mean, rest = per-row
- * scratch) and d_logits = (softmax - onehot)/rows (optional). */
+ * scratch) and d_logits = (softmax - onehot)/rows (optional).  A target outside [0, V) makes loss[0] NaN (the reference's
+ * nn.CrossEntropyLoss raises).  row_weight (optional, f32 [rows]): the policy-gradient form, loss = mean_r w_r * nll_r and
+ * d_logits scaled by w_r -- the REINFORCE generator loss of the SeqGAN update with w = the roll-out rewards. */
 int gic_xent(const void* logits, int dtype, int64_t rows, int32_t V, const int64_t* targets, float* loss,
-             void* d_logits, void* stream);
+             void* d_logits, const float* row_weight, void* stream);
+
+/* SeqGAN Monte-Carlo rewards (BASELINE config 5; no reference counterpart): mc_logits f32 [(L-1), N, B, R] = D's logits on the
+ * N roll-outs of every prefix length 1..L-1 (caption b, representation r), full_logits f32 [B, R] = D on the complete captions.
+ * rewards f32 [B, L]: reward[b, t] = mean_{n,r} sigmoid(mc_logits[t, n, b, r]) for t < L-1, mean_r sigmoid(full_logits[b, r]) for
+ * t = L-1. */
+int gic_rollout_rewards(const float* mc_logits, const float* full_logits, float* rewards, int B, int L, int N, int R, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * optimize(): clip_grad_norm_ + Adam (src/training.py:194-199, :24-26) over a flat f32 parameter arena.

@@ -56,8 +56,8 @@ def num_lstm_layers(gp: Params, prefix: str = "decoder.") -> int:
 def decoder_sample(gp: Params, features: Tensor, max_caption_len: int,
                    temperature: float, us: Optional[Sequence[Tensor]] = None,
                    pretrain: bool = False, prefix: str = "decoder.",
-                   force_ids: Optional[Tensor] = None, states: Optional[Tuple[Tensor, Tensor]] = None
-                   ) -> Tuple[Tensor, Tensor]:
+                   force_ids: Optional[Tensor] = None, states: Optional[Tuple[Tensor, Tensor]] = None,
+                   force_len: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """Decoder.sample (src/generator.py:55-81).
 
     ``us[t]`` is the U[0,1) draw of step t (shape [B,V]) that the reference
@@ -68,7 +68,8 @@ def decoder_sample(gp: Params, features: Tensor, max_caption_len: int,
 
     ``force_ids`` [B,L] (test aid, no reference counterpart): the trajectory to follow instead of the argmax -- the index is
     detached in the reference (:75), so the outputs' gradient on a GIVEN trajectory is the same function; used to compare
-    gradients with a bf16 run whose argmax differs at a near-tie.  ``states`` = (h0, c0), each [num_layers, B, H] (:55,61).
+    gradients with a bf16 run whose argmax differs at a near-tie; ``force_len`` [B] restricts the forcing of row b to its first
+    force_len[b] steps (prefix of a Monte-Carlo roll-out).  ``states`` = (h0, c0), each [num_layers, B, H] (:55,61).
     """
     nl = num_lstm_layers(gp, prefix)
     bsz = features.shape[0]
@@ -99,7 +100,7 @@ def decoder_sample(gp: Params, features: Tensor, max_caption_len: int,
             outs.append(pred)
         idx = pred.max(1)[1]                       # first maximal index
         if force_ids is not None:
-            idx = force_ids[:, t]
+            idx = force_ids[:, t] if force_len is None else torch.where(force_len > t, force_ids[:, t], idx)
         ids.append(idx)
         x = gp[f"{prefix}embed.weight"][idx.detach()]
     return torch.stack(outs, 1), torch.stack(ids, 1)

@@ -607,7 +607,7 @@ def test_fused_rollout_f32_matches_oracle(E, dev, shape):
     out, ids, st = eng.sample_fwd(params, feats.to(dev), Lc, T, noise_u=torch.stack(us).to(dev), states=dstates)
     assert st["part"] is not None
     ws = eng.alloc_bwd_ws(B, Lc, dev)
-    grads = eng.sample_bwd(params, st, out, ids, d_out.to(dev), T, ws=ws)
+    grads = eng.sample_bwd(params, st, out, ids, d_out.to(dev), T, ws=ws, phases=7)
     torch.cuda.synchronize()
     assert torch.equal(ids.cpu(), ids_ref), "token ids differ from the oracle"
     close(out, probs, rtol=1e-4, atol_scale=1e-6, what="probs")
@@ -699,7 +699,7 @@ def test_api_corners_match_reference_golden(E, dev):
     out, ids, st = eng.sample_fwd(params, g.t("feats").to(dev), Lc, m["T"], noise_u=g.t("st/u").to(dev),
                                   states=(g.t("h0").to(dev), g.t("c0").to(dev)))
     ws = eng.alloc_bwd_ws(B, Lc, dev)
-    grads = eng.sample_bwd(params, st, out, ids, g.t("st/d_out").to(dev), m["T"], ws=ws)
+    grads = eng.sample_bwd(params, st, out, ids, g.t("st/d_out").to(dev), m["T"], ws=ws, phases=7)
     d_h0, d_c0 = eng.state_grads(ws)
     torch.cuda.synchronize()
     assert torch.equal(ids.cpu(), g.t("st/ids"))

@@ -307,23 +307,19 @@ def test_cfg2_composed_step_bf16_vs_oracle():
         report["trunk_rel_l2/" + k] = rel_l2(t.float().permute(0, 3, 1, 2), taps[k])
     # the plan's own feature buffer still holds this step's pooled output (no later pass ran)
     report["trunk_rel_l2/pooled"] = rel_l2(pb["feat"].float(), feat)
-    for k, lim in budget.items():
-        assert report["trunk_rel_l2/" + k] < lim, f"trunk {k}: rel L2 {report['trunk_rel_l2/' + k]:.3e} over its budget {lim}"
+    failures = [f"trunk {k}: rel L2 {report['trunk_rel_l2/' + k]:.3e} over its budget {lim}" for k, lim in budget.items()
+                if not report["trunk_rel_l2/" + k] < lim]
 
     # ---- roll-out: token ids (bf16 near-ties may flip an argmax; everything downstream then follows the GPU's trajectory)
     ids = out["ids"].cpu()
     match = float((ids == ref["ids"]).float().mean())
     report["id_match_rate"] = match
-    assert match >= 0.9
     if match < 1.0:
         ref = O.adv_step(dict(gp), dict(dp), caps, us, masks, T, "standard", 5.0, None, None, trunk_feat=feat, force_ids=ids)
     report["probs_rel_l2"] = rel_l2(out["probs"].float(), ref["probs"])
-    assert report["probs_rel_l2"] < 5e-2
     # ---- losses: rel 2e-2 (d_loss) / 3e-2 (g_loss), SURVEY §8(c)
     gl, dl = (float(v) for v in out["losses"])
     report["g_loss"], report["g_loss_ref"], report["d_loss"], report["d_loss_ref"] = gl, ref["g_loss"], dl, ref["d_loss"]
-    assert dl == pytest.approx(ref["d_loss"], rel=2e-2)
-    assert gl == pytest.approx(ref["g_loss"], rel=3e-2)
     # ---- gradients: relative L2 per tensor, D 8e-2, G 8e-2 (encoder head 1e-1: it sees the trunk's 5e-2 feature error)
     dgot = {n: p.grad for n, p in zip(disc_param_names(3), inst.disc.param_list())}
     ggot = {n: p.grad for n, p in zip(dec_param_names(1), inst.gen.decoder.param_list())}
@@ -331,12 +327,14 @@ def test_cfg2_composed_step_bf16_vs_oracle():
                  "encoder.bn.weight": enc.bn.weight.grad, "encoder.bn.bias": enc.bn.bias.grad})
     for n in ("highway.weight", "feature2out.weight", "out2logits.weight", "embeddings.weight", "convs.0.weight", "convs.2.weight"):
         report["d_grad_rel_l2/" + n] = rel_l2(dgot[n], ref["d_grads_raw"][n])
-        assert report["d_grad_rel_l2/" + n] < 8e-2, f"{n}: rel L2 {report['d_grad_rel_l2/' + n]}"
+        if not report["d_grad_rel_l2/" + n] < 8e-2:
+            failures.append(f"{n}: rel L2 {report['d_grad_rel_l2/' + n]}")
     for n, lim in (("decoder.linear.weight", 8e-2), ("decoder.linear.bias", 8e-2), ("decoder.lstm.weight_hh_l0", 8e-2),
                    ("decoder.lstm.weight_ih_l0", 8e-2), ("decoder.embed.weight", 8e-2), ("encoder.linear.weight", 1e-1), ("encoder.bn.weight", 1e-1),
                    ("encoder.bn.bias", 1e-1)):
         report["g_grad_rel_l2/" + n] = rel_l2(ggot[n], ref["g_grads_raw"][n])
-        assert report["g_grad_rel_l2/" + n] < lim, f"{n}: rel L2 {report['g_grad_rel_l2/' + n]} (limit {lim})"
+        if not report["g_grad_rel_l2/" + n] < lim:
+            failures.append(f"{n}: rel L2 {report['g_grad_rel_l2/' + n]} (limit {lim})")
     print("cfg2 composed parity:", json.dumps(report))
     try:
         os.makedirs("gpurun_out", exist_ok=True)
@@ -344,3 +342,8 @@ def test_cfg2_composed_step_bf16_vs_oracle():
             json.dump(report, fh, indent=1)
     except OSError:
         pass
+    assert match >= 0.9
+    assert report["probs_rel_l2"] < 5e-2
+    assert dl == pytest.approx(ref["d_loss"], rel=2e-2)
+    assert gl == pytest.approx(ref["g_loss"], rel=3e-2)
+    assert not failures, failures
