@@ -79,13 +79,6 @@ class FusedAdvStep:
             ev.record(stream)
             self.trace.append((name, ev))
 
-    def _roll_stream(self, dev):
-        if os.environ.get("GIC_NO_ROLLOUT_PRIORITY"):
-            return None
-        if getattr(self, "_s_roll", None) is None:
-            self._s_roll = torch.cuda.Stream(device=dev, priority=-1)
-        return self._s_roll
-
     def _streams(self, dev):
         if getattr(self, "_s_real", None) is None:
             self._s_real = torch.cuda.Stream(device=dev)     # D(real) forward: independent of the generator
@@ -156,22 +149,10 @@ class FusedAdvStep:
         self._mark("encoder done", main)
         seed = 0 if noise_u is not None else SEEDS.next()
         main.wait_event(ev_gprep)
-        s_roll = self._roll_stream(dev) if overlap else None
-        if s_roll is not None:
-            # the roll-out is a chain of 41 small dependent launches, each of which has to win CU slots from the look-ahead trunk
-            # pass's wide convolution grids: it runs on a HIGH-PRIORITY stream, so freed slots go to it first (the trunk only loses
-            # the slots the roll-out actually needs, for the ~0.5 ms it lasts)
-            ev_feats = main.record_event()
-            with torch.cuda.stream(s_roll):
-                s_roll.wait_event(ev_feats)
-                probs, ids, dst = self.dec.sample_fwd(gparams, feats, L, T, False, noise_u, seed, state=buf["dec_state"],
-                                                      out=buf["probs"], ids=buf["ids"])
-                ev_roll = s_roll.record_event()
-            feats.record_stream(s_roll)
-            main.wait_event(ev_roll)
-        else:
-            probs, ids, dst = self.dec.sample_fwd(gparams, feats, L, T, False, noise_u, seed, state=buf["dec_state"],
-                                                  out=buf["probs"], ids=buf["ids"])
+        # (measured: issuing the roll-out from a high-priority stream does not win it CU slots from the look-ahead trunk pass --
+        # it finished only after the whole trunk pass -- so it stays on the main stream)
+        probs, ids, dst = self.dec.sample_fwd(gparams, feats, L, T, False, noise_u, seed, state=buf["dec_state"],
+                                              out=buf["probs"], ids=buf["ids"])
         self._mark("roll-out done", main)
 
         # ---- D(fake), D(gen) (training.py:163-164): one pass up to the highway layer, two dropout draws + heads

@@ -1,0 +1,81 @@
+"""CPU oracle of the visual-attention caption decoder (BASELINE.json config 4).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  NO REFERENCE COUNTERPART: the reference's decoder sees the image only through the
+pooled feature fed as the first LSTM input (src/generator.py:19-25, 55-81); its report (NLP_Report.pdf p.4, 4.2) describes
+attention over grid features for a transformer that is not in the code drop.  This is the build's own definition: the reference's
+roll-out loop (src/generator.py:55-81: Gumbel-softmax relaxation, greedy argmax feedback, temperature multiplied in) with a
+Show-Attend-Tell soft attention (Xu et al., ICML 2015, eq. 4-6, 13) over the trunk's feature MAP inserted in front of the LSTM:
+
+    a_i            the trunk's last feature map [B, P = h*w, C] (frozen, src/generator.py:21: no gradient into the trunk)
+    fp_i = W_f a_i + b_f                                   [A]   (computed once per caption)
+    e_ti = w_a . tanh(fp_i + W_h h_{t-1})                         additive attention energy
+    alpha_t = softmax_i(e_t);   z_t = sum_i alpha_ti a_i   [C]   context vector
+    (h_t, c_t) = LSTMCell([x_t ; z_t], (h_{t-1}, c_{t-1}))        x_0 = features (encoder head), x_t = embed(argmax_{t-1})
+    o_t = W_out h_t + b_out;  p_t = softmax((o_t + gumbel(u_t)) * T)      exactly src/generator.py:68-76
+
+Parameters added to the reference's decoder: decoder.attn.w_f [A,C], .b_f [A], .w_h [A,H], .w_a [A]; decoder.lstm.weight_ih_l0 is
+[4H, E + C].  One LSTM layer.  Differentiable plain torch: autograd of this file is the gradient oracle.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import cpu_step as O
+
+Tensor = torch.Tensor
+
+
+def make_attn_params(vocab: int, embed: int, hidden: int, feat_c: int, attn: int, gen: torch.Generator) -> O.Params:
+    u = O.init_uniform
+    return {
+        "decoder.embed.weight": u((vocab, embed), gen),
+        "decoder.lstm.weight_ih_l0": u((4 * hidden, embed + feat_c), gen), "decoder.lstm.weight_hh_l0": u((4 * hidden, hidden), gen),
+        "decoder.lstm.bias_ih_l0": u((4 * hidden,), gen), "decoder.lstm.bias_hh_l0": u((4 * hidden,), gen),
+        "decoder.linear.weight": u((vocab, hidden), gen), "decoder.linear.bias": u((vocab,), gen),
+        "decoder.attn.w_f": u((attn, feat_c), gen), "decoder.attn.b_f": u((attn,), gen),
+        "decoder.attn.w_h": u((attn, hidden), gen), "decoder.attn.w_a": u((attn,), gen),
+    }
+
+
+def attention(gp: O.Params, fmap: Tensor, fproj: Tensor, h_prev: Tensor, prefix: str = "decoder.") -> Tuple[Tensor, Tensor]:
+    """(context z [B,C], weights alpha [B,P]) for one step."""
+    hp = h_prev @ gp[f"{prefix}attn.w_h"].t()                                   # [B,A]
+    e = torch.tanh(fproj + hp.unsqueeze(1)) @ gp[f"{prefix}attn.w_a"]           # [B,P]
+    alpha = torch.softmax(e, dim=1)
+    z = (alpha.unsqueeze(2) * fmap).sum(1)
+    return z, alpha
+
+
+def attn_decoder_sample(gp: O.Params, features: Tensor, fmap: Tensor, max_caption_len: int, temperature: float,
+                        us: Optional[Sequence[Tensor]] = None, pretrain: bool = False, prefix: str = "decoder.",
+                        force_ids: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """Returns (outputs [B,L,V], ids [B,L], alphas [B,L,P]); see the module docstring."""
+    bsz = features.shape[0]
+    hid = gp[f"{prefix}lstm.weight_hh_l0"].shape[1]
+    fproj = fmap @ gp[f"{prefix}attn.w_f"].t() + gp[f"{prefix}attn.b_f"]        # [B,P,A]
+    h = features.new_zeros(bsz, hid)
+    c = features.new_zeros(bsz, hid)
+    x = features
+    outs: List[Tensor] = []
+    ids: List[Tensor] = []
+    alphas: List[Tensor] = []
+    for t in range(max_caption_len):
+        z, alpha = attention(gp, fmap, fproj, h, prefix)
+        h, c = O.lstm_cell(torch.cat([x, z], 1), h, c, gp[f"{prefix}lstm.weight_ih_l0"], gp[f"{prefix}lstm.weight_hh_l0"],
+                           gp[f"{prefix}lstm.bias_ih_l0"], gp[f"{prefix}lstm.bias_hh_l0"])
+        o = h @ gp[f"{prefix}linear.weight"].t() + gp[f"{prefix}linear.bias"]
+        if pretrain:
+            outs.append(o)
+            pred = torch.softmax(o, dim=-1)
+        else:
+            pred = torch.softmax((o + O.gumbel_from_uniform(us[t])) * temperature, dim=-1)
+            outs.append(pred)
+        idx = pred.max(1)[1]
+        if force_ids is not None:
+            idx = force_ids[:, t]
+        ids.append(idx)
+        alphas.append(alpha)
+        x = gp[f"{prefix}embed.weight"][idx.detach()]
+    return torch.stack(outs, 1), torch.stack(ids, 1), torch.stack(alphas, 1)
