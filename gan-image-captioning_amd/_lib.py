@@ -55,6 +55,30 @@ class DecoderBwdWs(C.Structure):
                 ("dxh", c_void_p * MAX_LAYERS), ("dc", c_void_p * MAX_LAYERS)]
 
 
+class AttnDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "L", "V", "E", "H", "C", "P", "A", "dtype")]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("embed", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out", "w_f", "b_f", "w_h", "w_a")]
+
+
+class AttnGrads(C.Structure):
+    _fields_ = AttnParams._fields_ + [("features", c_void_p)]
+
+
+class AttnShadow(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("wcat", "bsum", "wout", "wcat_t", "wf", "wh")]
+
+
+class AttnState(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("xh", "gates", "c", "hout", "part", "fproj", "alpha", "hproj")]
+
+
+class AttnBwdWs(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("dlogits", "dhout", "dgates", "dc", "dz", "dh_extra", "dhproj", "dfproj", "dfproj_act", "dwa_rows", "dx")]
+
+
 class DiscDims(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("V", C.c_int32), ("De", C.c_int32), ("R", C.c_int32),
                 ("nconv", C.c_int32), ("fsize", C.c_int32 * MAX_CONVS), ("nfilt", C.c_int32 * MAX_CONVS),
@@ -110,6 +134,11 @@ _SIGNATURES = {
                                          _P(DecoderBwdWs), c_void_p, c_void_p, c_void_p, C.c_float, C.c_int,
                                          _P(DecoderGrads), C.c_int, c_void_p]),
     "gic_debug_decoder_step": (None, [C.c_int]),
+    "gic_attn_prepare": (C.c_int, [_P(AttnDims), _P(AttnParams), _P(AttnShadow), c_void_p]),
+    "gic_attn_sample_fwd": (C.c_int, [_P(AttnDims), _P(AttnParams), _P(AttnShadow), _P(AttnState), c_void_p, c_void_p, c_void_p, C.c_uint64,
+                                      C.c_float, C.c_int, c_void_p, c_void_p, c_void_p]),
+    "gic_attn_sample_bwd": (C.c_int, [_P(AttnDims), _P(AttnParams), _P(AttnShadow), _P(AttnState), _P(AttnBwdWs), c_void_p, c_void_p, c_void_p,
+                                      c_void_p, C.c_float, C.c_int, _P(AttnGrads), c_void_p]),
     "gic_embedding_fwd": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, c_void_p]),
     "gic_embedding_bwd": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int, c_void_p]),
     "gic_disc_prepare": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), c_void_p]),

@@ -430,25 +430,10 @@ int sample_bwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
   const int B = c.B, L = c.L, V = c.V, E = c.E, H = c.H, NL = c.NL;
   const long BL = (long)B * L;
   const int pw_grid = cdiv((long)B * H, 256);
-  // 1. d_logits [B,L,V]
-  const void* dlog = pretrain ? d_out : (const void*)ws->dlogits;
-  if (!pretrain && (phases & GIC_DECODER_BWD_OUTPUT)) {
-    hipLaunchKernelGGL((softmax_bwd_kernel<TA>), dim3((unsigned)BL), dim3(256), 0, stream, (const TA*)probs,
-                       (const TA*)d_out, (TA*)ws->dlogits, temperature, V);
-    GIC_CHECK_LAUNCH("softmax_bwd");
-  }
-  // 2. d_hout = d_logits W_out ; dW_out = d_logits^T hout ; db_out = colsum(d_logits)
-  if (phases & GIC_DECODER_BWD_OUTPUT) {
-    GemmDesc g;
-    g.A = dlog; g.lda = V; g.a_kc = 1; g.B = S->wout; g.ldb = H; g.b_kc = 0; g.C = ws->dhout; g.ldc = H;
-    g.M = (int)BL; g.N = H; g.K = V; g.in_dtype = c.dt; g.out_dtype = DT_F32;
-    GIC_PROPAGATE(gemm(g, stream));
-    GemmDesc w;
-    w.A = dlog; w.lda = V; w.a_kc = 0; w.B = st->hout; w.ldb = H; w.b_kc = 0; w.C = G->w_out; w.ldc = H;
-    w.M = V; w.N = H; w.K = (int)BL; w.in_dtype = c.dt; w.out_dtype = DT_F32;
-    GIC_PROPAGATE(gemm(w, stream));
-    GIC_PROPAGATE(colsum(dlog, c.dt, V, BL, V, G->b_out, nullptr, 0, stream));
-  }
+  // 1. + 2. output layer: d_logits [B,L,V], d_hout = d_logits W_out, dW_out = d_logits^T hout, db_out = colsum(d_logits)
+  if (phases & GIC_DECODER_BWD_OUTPUT)
+    GIC_PROPAGATE(decoder_output_bwd(c.dt, B, L, V, H, probs, d_out, temperature, pretrain, ws->dlogits, S->wout, st->hout, ws->dhout,
+                                     G->w_out, G->b_out, stream));
   if (!(phases & GIC_DECODER_BWD_RECURRENT)) return GIC_OK;
   // 3. BPTT
   bool fused = decoder_step_supported(c.dt, 4, 8, H, NL) && H % 2 == 0 && B <= 512;
@@ -526,8 +511,7 @@ int sample_bwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
   }
   // 5. inputs: d_features = dx_0 ; d_embed[ids[b,t-1]] += dx_t (t >= 1)  (generator.py:75: index detached)
   GIC_PROPAGATE(cast2d(ws->dxh[0], DT_F32, c.ldx(0), G->features, DT_F32, E, B, E, stream));
-  GIC_PROPAGATE(fill_zero(G->embed, (size_t)V * E * sizeof(float), stream));
-  // the scatter-add itself (embed_scatter_time_kernel) is enqueued by the caller below
+  // the embedding scatter-add (embed_scatter_time) is enqueued by the caller below
   return GIC_OK;
 }
 
@@ -546,6 +530,45 @@ __global__ void embed_scatter_time_kernel(const float* __restrict__ dxh0, long l
 }
 
 }  // namespace
+
+// Output layer of the decoder, backward (shared by the LSTM and the attention decoder): softmax/Gumbel backward (adversarial mode),
+// d_hout, and the complete gradients of the vocabulary projection.
+int decoder_output_bwd(int dt, int B, int L, int V, int H, const void* probs, const void* d_out, float temperature, int pretrain,
+                       void* dlogits_ws, const void* wout, const void* hout, float* dhout, float* d_wout, float* d_bout, hipStream_t stream) {
+  const long BL = (long)B * L;
+  const void* dlog = pretrain ? d_out : (const void*)dlogits_ws;
+  if (!pretrain) {
+    if (dt == DT_F32)
+      hipLaunchKernelGGL((softmax_bwd_kernel<float>), dim3((unsigned)BL), dim3(256), 0, stream, (const float*)probs, (const float*)d_out,
+                         (float*)dlogits_ws, temperature, V);
+    else
+      hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t>), dim3((unsigned)BL), dim3(256), 0, stream, (const bf16_t*)probs, (const bf16_t*)d_out,
+                         (bf16_t*)dlogits_ws, temperature, V);
+    GIC_CHECK_LAUNCH("softmax_bwd");
+  }
+  GemmDesc g;
+  g.A = dlog; g.lda = V; g.a_kc = 1; g.B = wout; g.ldb = H; g.b_kc = 0; g.C = dhout; g.ldc = H;
+  g.M = (int)BL; g.N = H; g.K = V; g.in_dtype = dt; g.out_dtype = DT_F32;
+  GIC_PROPAGATE(gemm(g, stream));
+  GemmDesc w;
+  w.A = dlog; w.lda = V; w.a_kc = 0; w.B = hout; w.ldb = H; w.b_kc = 0; w.C = d_wout; w.ldc = H;
+  w.M = V; w.N = H; w.K = (int)BL; w.in_dtype = dt; w.out_dtype = DT_F32;
+  GIC_PROPAGATE(gemm(w, stream));
+  return colsum(dlog, dt, V, BL, V, d_bout, nullptr, 0, stream);
+}
+
+// d_embed[ids[b, t-1]] += dx_t (t >= 1) over a zeroed table (generator.py:75: the index is detached); dx rows at dx + (t*B + b)*ld
+int embed_scatter_time(const float* dx, long ld, const int64_t* ids, float* d_embed, int B, int L, int E, int V, hipStream_t stream) {
+  GIC_PROPAGATE(fill_zero(d_embed, (size_t)V * E * sizeof(float), stream));
+  if (L > 1) {
+    const long total = (long)(L - 1) * B * E;
+    const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(embed_scatter_time_kernel, dim3(grid), dim3(256), 0, stream, dx, ld, ids, d_embed, B, L, E, V);
+    GIC_CHECK_LAUNCH("embed_scatter_time");
+  }
+  return GIC_OK;
+}
+
 }  // namespace gic
 
 using namespace gic;
@@ -766,13 +789,8 @@ int gic_decoder_sample_bwd(const gic_decoder_dims* dims, const gic_decoder_param
               ? sample_bwd_t<float>(c, P, S, st, ws, probs, ids, d_out, temperature, pretrain, G, phases, stream)
               : sample_bwd_t<bf16_t>(c, P, S, st, ws, probs, ids, d_out, temperature, pretrain, G, phases, stream);
   GIC_PROPAGATE(s);
-  if (c.L > 1 && (phases & GIC_DECODER_BWD_RECURRENT)) {
-    const long total = (long)(c.L - 1) * c.B * c.E;
-    const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-    hipLaunchKernelGGL(embed_scatter_time_kernel, dim3(grid), dim3(256), 0, stream, (const float*)ws->dxh[0], c.ldx(0), ids,
-                       G->embed, c.B, c.L, c.E, c.V);
-    GIC_CHECK_LAUNCH("embed_scatter_time");
-  }
+  if (phases & GIC_DECODER_BWD_RECURRENT)
+    GIC_PROPAGATE(embed_scatter_time((const float*)ws->dxh[0], c.ldx(0), ids, G->embed, c.B, c.L, c.E, c.V, stream));
   return GIC_OK;
 }
 

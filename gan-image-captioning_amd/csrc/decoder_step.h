@@ -33,6 +33,7 @@ struct LstmStepArgs {
   int B = 0, H = 0, din = 0; long ldx = 0;
   // layer 0, t > 0: x_t = embed[id_{t-1}], id = argmax over the previous step's partials (or the forced trajectory)
   int gather = 0;
+  int gw = 0;                        // width of the gathered x (= embedding dim): columns [0, gw) of the input; 0 = din
   const float* embed = nullptr; int V = 0;
   const unsigned long long* rowkey = nullptr;      // [B] argmax keys of step t-1 (vocab_step's atomicMax; see row_key())
   const int64_t* force_ids = nullptr; long force_stride = 0; const int32_t* force_len = nullptr; int tprev = 0;
@@ -70,6 +71,7 @@ struct SampleFinishArgs {
 // the 8 waves, operands straight from L2 (the k-contiguous operand of W is the transposed weight image wcat_t).
 struct LstmBwdStepArgs {
   const float* dh_above = nullptr; long ld_above = 0;   // f32 rows (top layer: dhout[b, t, :]) or null
+  const float* dh_extra = nullptr;                      // f32 [B, H] added as is (attention decoder: gradient through W_h h_{t-1}) or null
   const void* dg_next = nullptr;                        // act [B, 4H] dgates of step t+1, this layer (null at t = L-1)
   const void* w_rec = nullptr;                          // act rows j of wcat_t (+ din rows): [H][4H], W_hh^T
   const void* dg_up = nullptr;                          // act [B, 4H] dgates of step t, layer l+1 (null for the top layer)

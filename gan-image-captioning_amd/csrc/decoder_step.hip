@@ -172,6 +172,7 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmStepArgs a, co
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int ldx = (int)a.ldx;
+  const int gw = a.gw ? a.gw : a.din;
   for (int kc0 = 0; kc0 < ldx; kc0 += KC) {
     const int kc = min(KC, ldx - kc0);
     if (kc0) __syncthreads();                          // every wave has read the previous chunk
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmStepArgs a, co
         const int k = kc0 + cc * VE;
         v[i] = (u32x4){0u, 0u, 0u, 0u};
         if (c < total && b0 + row < a.B && !(a.dbg & 2)) {
-          if (a.gather && k < a.din) v[i] = chunk_from_f32<TA>(a.embed + (long)ids_s[row] * a.din + k);   // din % 8 == 0: never straddles x | h
+          if (a.gather && k < gw) v[i] = chunk_from_f32<TA>(a.embed + (long)ids_s[row] * gw + k);   // gw % 8 == 0: never straddles x | rest
           else v[i] = *(gptr_u4)(xh + (long)(b0 + row) * a.ldx + k);
         }
       }
@@ -545,6 +546,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(const LstmBwdStepArg
     const int b = b0 + rb, j = j0 + u;
     if (b < a.B && j < a.H) {
       float dh = a.dh_above ? a.dh_above[(long)b * a.ld_above + j] : 0.f;
+      if (a.dh_extra) dh += a.dh_extra[(long)b * a.H + j];
 #pragma unroll
       for (int ww = 0; ww < 8; ++ww) dh += red[ww][rb][u];
       const float* g = a.gates + (long)b * K;
@@ -608,7 +610,8 @@ void decoder_step_debug(int v) { g_step_dbg = v; }
 
 int lstm_step(const LstmStepArgs& a, int dtype, hipStream_t stream) {
   GIC_CHECK_ARG(a.xh_t && a.xh_next && a.wcat && a.bsum && a.c_prev && a.c_new, "lstm_step: null buffer");
-  GIC_CHECK_ARG(a.B > 0 && a.H > 0 && a.din > 0 && a.ldx == (long)a.din + a.H && a.ldx % 8 == 0 && a.din % 8 == 0, "lstm_step: bad dims");
+  GIC_CHECK_ARG(a.B > 0 && a.H > 0 && a.din > 0 && a.ldx == (long)a.din + a.H && a.ldx % 8 == 0 && a.din % 8 == 0 && a.gw % 8 == 0 && a.gw <= a.din,
+                "lstm_step: bad dims");
   GIC_CHECK_ARG(!a.gather || (a.embed && a.V > 0 && (a.rowkey || a.force_ids)), "lstm_step: bad gather arguments");
   const dim3 grid((unsigned)cdiv(a.H, kUnitsPerBlock), (unsigned)cdiv(a.B, kStepRows));
   LstmStepArgs b = a;

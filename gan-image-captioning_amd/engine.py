@@ -637,3 +637,148 @@ def clip_adam(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, clip_no
                                    float(beta2), float(eps), float(clip_norm), ptr(step_count), ptr(norm_out), ptr(partials),
                                    stream_ptr()), "gic_clip_adam")
     bump_param_epoch()
+
+
+# ------------------------------------------------------------------------------------------ visual-attention decoder
+class AttnDecoderEngine:
+    """gic_attn_sample_fwd / bwd (gicap.h): the reference's roll-out loop with soft attention over the trunk's feature map
+    (BASELINE config 4; no reference counterpart, oracle/cpu_attention.py).
+    params order: [embed, w_ih, w_hh, b_ih, b_hh, w_out, b_out, w_f, b_f, w_h, w_a]."""
+
+    NAMES = ("embed", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out", "w_f", "b_f", "w_h", "w_a")
+
+    def __init__(self, vocab: int, embed: int, hidden: int, feat_c: int, positions: int, attn: int, dtype: int):
+        self.V, self.E, self.H, self.C, self.P, self.A, self.dt = vocab, embed, hidden, feat_c, positions, attn, dtype
+        self.act = TORCH_DTYPE[dtype]
+        self.ldx = embed + feat_c + hidden
+        self._shadow = None
+        self._shadow_key = None
+
+    def dims(self, B: int, Lc: int) -> L.AttnDims:
+        return L.AttnDims(B, Lc, self.V, self.E, self.H, self.C, self.P, self.A, self.dt)
+
+    def _pstruct(self, params, cls=L.AttnParams, extra=None):
+        s = cls()
+        for n, p in zip(self.NAMES, params):
+            setattr(s, n, ptr(p))
+        if extra is not None:
+            s.features = ptr(extra)
+        return s
+
+    def check_params(self, params) -> None:
+        if len(params) != len(self.NAMES):
+            raise ValueError("attention decoder expects %d parameter tensors" % len(self.NAMES))
+        require_gpu(*params)
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError("attention decoder parameters must be contiguous float32 (master weights)")
+
+    def prepare(self, params):
+        key = _key(params)
+        if self._shadow is not None and key == self._shadow_key:
+            return self._shadow
+        dev = params[0].device
+        if self._shadow is None:
+            self._shadow = {
+                "wcat": torch.empty(4 * self.H, self.ldx, device=dev, dtype=self.act),
+                "bsum": torch.empty(4 * self.H, device=dev, dtype=torch.float32),
+                "wout": None if self.dt == L.F32 else torch.empty(self.V, self.H, device=dev, dtype=self.act),
+                "wcat_t": torch.empty(self.ldx, 4 * self.H, device=dev, dtype=self.act),
+                "wf": torch.empty(self.A, self.C, device=dev, dtype=self.act),
+                "wh": torch.empty(self.A, self.H, device=dev, dtype=self.act),
+            }
+        L.check(L.load().gic_attn_prepare(C.byref(self.dims(1, 1)), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)),
+                                          stream_ptr()), "gic_attn_prepare")
+        self._shadow_key = key
+        return self._shadow
+
+    def _shadow_struct(self, params) -> L.AttnShadow:
+        sh = self._shadow
+        s = L.AttnShadow()
+        s.wcat, s.bsum, s.wcat_t, s.wf, s.wh = ptr(sh["wcat"]), ptr(sh["bsum"]), ptr(sh["wcat_t"]), ptr(sh["wf"]), ptr(sh["wh"])
+        s.wout = ptr(params[5]) if sh["wout"] is None else ptr(sh["wout"])
+        return s
+
+    def alloc_state(self, B: int, Lc: int, dev):
+        f32 = torch.float32
+        nblk = (self.V + 63) // 64
+        return {
+            "xh": torch.empty(Lc + 1, B, self.ldx, device=dev, dtype=self.act),
+            "gates": torch.empty(Lc, B, 4 * self.H, device=dev, dtype=f32),
+            "c": torch.empty(Lc + 1, B, self.H, device=dev, dtype=f32),
+            "hout": torch.empty(B, Lc, self.H, device=dev, dtype=self.act),
+            "part": torch.empty(2 * Lc * B * nblk + 2 * Lc * B + 2, device=dev, dtype=f32),
+            "fproj": torch.empty(B, self.P, self.A, device=dev, dtype=self.act),
+            "alpha": torch.empty(Lc, B, self.P, device=dev, dtype=f32),
+            "hproj": torch.empty(Lc, B, self.A, device=dev, dtype=f32),
+        }
+
+    def _state_struct(self, st) -> L.AttnState:
+        s = L.AttnState()
+        for k in ("xh", "gates", "c", "hout", "part", "fproj", "alpha", "hproj"):
+            setattr(s, k, ptr(st[k]))
+        return s
+
+    def sample_fwd(self, params, features, fmap, Lc: int, temperature: float, pretrain: bool = False, noise_u=None, seed: int = 0):
+        self.check_params(params)
+        require_gpu(features, fmap, noise_u)
+        B = features.shape[0]
+        if tuple(features.shape) != (B, self.E) or features.dtype != torch.float32:
+            raise ValueError(f"features must be float32 [B,{self.E}]")
+        if tuple(fmap.shape) != (B, self.P, self.C):
+            raise ValueError(f"fmap must be [B, P={self.P}, C={self.C}], got {tuple(fmap.shape)}")
+        fmap = fmap.contiguous()
+        if fmap.dtype != self.act:
+            dst = torch.empty(fmap.shape, device=fmap.device, dtype=self.act)
+            cast2d(fmap.float() if fmap.dtype not in (torch.float32, torch.bfloat16) else fmap, dst, B * self.P, self.C, self.C, self.C)
+            fmap = dst
+        if noise_u is not None:
+            if tuple(noise_u.shape) != (Lc, B, self.V) or noise_u.dtype != torch.float32:
+                raise ValueError(f"noise_u must be float32 [L={Lc},B={B},V={self.V}]")
+            noise_u = noise_u.contiguous()
+        dev = features.device
+        self.prepare(params)
+        st = self.alloc_state(B, Lc, dev)
+        out = torch.empty(B, Lc, self.V, device=dev, dtype=self.act)
+        ids = torch.empty(B, Lc, device=dev, dtype=torch.int64)
+        L.check(L.load().gic_attn_sample_fwd(
+            C.byref(self.dims(B, Lc)), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
+            ptr(features.contiguous()), ptr(fmap), ptr(noise_u), int(seed) & (2 ** 64 - 1), float(temperature), int(bool(pretrain)),
+            ptr(out), ptr(ids), stream_ptr()), "gic_attn_sample_fwd")
+        st["fmap"] = fmap
+        return out, ids, st
+
+    def sample_bwd(self, params, st, out, ids, d_out, temperature: float, pretrain: bool = False):
+        """Returns [grads in NAMES order ..., d_features]."""
+        B, Lc = ids.shape
+        dev = out.device
+        f32 = torch.float32
+        if d_out.dtype != self.act:
+            t = d_out.contiguous()
+            dst = torch.empty(t.shape, device=dev, dtype=self.act)
+            cast2d(t, dst, t.numel() // self.V, self.V, self.V, self.V)
+            d_out = dst
+        d_out = d_out.contiguous()
+        self.prepare(params)
+        ws = {
+            "dlogits": torch.empty(B, Lc, self.V, device=dev, dtype=self.act),
+            "dhout": torch.empty(B, Lc, self.H, device=dev, dtype=f32),
+            "dgates": torch.empty(Lc, B, 4 * self.H, device=dev, dtype=self.act),
+            "dc": torch.empty(B, self.H, device=dev, dtype=f32),
+            "dz": torch.empty(B, self.C, device=dev, dtype=f32),
+            "dh_extra": torch.empty(B, self.H, device=dev, dtype=f32),
+            "dhproj": torch.empty(Lc, B, self.A, device=dev, dtype=self.act),
+            "dfproj": torch.empty(B, self.P, self.A, device=dev, dtype=f32),
+            "dfproj_act": None if self.dt == L.F32 else torch.empty(B, self.P, self.A, device=dev, dtype=self.act),
+            "dwa_rows": torch.empty(B, self.A, device=dev, dtype=f32),
+            "dx": torch.empty(Lc * B, self.E, device=dev, dtype=f32),
+        }
+        w = L.AttnBwdWs()
+        for k, v in ws.items():
+            setattr(w, k, ptr(v))
+        grads = [torch.empty_like(p) for p in params] + [torch.empty(B, self.E, device=dev, dtype=f32)]
+        L.check(L.load().gic_attn_sample_bwd(
+            C.byref(self.dims(B, Lc)), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
+            C.byref(w), ptr(st["fmap"]), ptr(out), ptr(ids), ptr(d_out), float(temperature), int(bool(pretrain)),
+            C.byref(self._pstruct(grads[:-1], L.AttnGrads, grads[-1])), stream_ptr()), "gic_attn_sample_bwd")
+        return grads

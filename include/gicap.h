@@ -190,6 +190,82 @@ int gic_embedding_bwd(const float* d_out, const int64_t* ids, float* d_weight, i
                       int zero_first, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Visual-attention caption decoder (BASELINE config 4; NO reference counterpart: the reference's decoder, src/generator.py:27-96,
+ * sees the image only through the pooled feature).  The reference's roll-out loop (generator.py:55-81) with a Show-Attend-Tell soft
+ * attention over the trunk's feature map in front of a one-layer LSTM; definition + CPU oracle: oracle/cpu_attention.py.
+ *   fp_i = W_f a_i + b_f;  e_ti = w_a . tanh(fp_i + W_h h_{t-1});  alpha_t = softmax_i e_t;  z_t = sum_i alpha_ti a_i;
+ *   LSTM input [x_t ; z_t];  logits, Gumbel, softmax, argmax feedback as gic_decoder_sample_fwd.
+ */
+typedef struct gic_attn_dims {
+  int32_t B, L, V, E, H;       /* as gic_decoder_dims */
+  int32_t C, P, A;             /* feature channels, positions (h*w) of the feature map, attention width */
+  int32_t dtype;
+} gic_attn_dims;
+
+typedef struct gic_attn_params {         /* f32 master weights */
+  const float* embed;                    /* decoder.embed.weight        [V,E]     */
+  const float* w_ih;                     /* decoder.lstm.weight_ih_l0   [4H,E+C]  */
+  const float* w_hh;                     /* decoder.lstm.weight_hh_l0   [4H,H]    */
+  const float* b_ih; const float* b_hh;  /* [4H] */
+  const float* w_out; const float* b_out;/* decoder.linear              [V,H],[V] */
+  const float* w_f; const float* b_f;    /* decoder.attn.w_f / b_f      [A,C],[A] */
+  const float* w_h;                      /* decoder.attn.w_h            [A,H]     */
+  const float* w_a;                      /* decoder.attn.w_a            [A]       */
+} gic_attn_params;
+
+typedef struct gic_attn_grads {          /* f32, shapes of gic_attn_params; all overwritten */
+  float* embed; float* w_ih; float* w_hh; float* b_ih; float* b_hh; float* w_out; float* b_out;
+  float* w_f; float* b_f; float* w_h; float* w_a;
+  float* features;                       /* d(features) [B,E] */
+} gic_attn_grads;
+
+typedef struct gic_attn_shadow {         /* compute-dtype weight images, refreshed by gic_attn_prepare */
+  void* wcat;                            /* act [4H, E+C+H] = [w_ih | w_hh] */
+  float* bsum;                           /* [4H] */
+  void* wout;                            /* act [V,H] (may alias params.w_out in f32 mode) */
+  void* wcat_t;                          /* act [E+C+H, 4H] */
+  void* wf;                              /* act [A,C] */
+  void* wh;                              /* act [A,H] */
+} gic_attn_shadow;
+
+typedef struct gic_attn_state {          /* saved for backward + scratch (caller-owned) */
+  void* xh;                              /* act [(L+1), B, E+C+H]: x_t | z_t | h_{t-1} */
+  float* gates;                          /* [L, B, 4H] */
+  float* c;                              /* [(L+1), B, H] */
+  void* hout;                            /* act [B, L, H] */
+  float* part;                           /* scratch of the fused step kernels, as gic_decoder_state.part */
+  void* fproj;                           /* act [B, P, A] */
+  float* alpha;                          /* [L, B, P] attention weights */
+  float* hproj;                          /* [L, B, A] W_h h_{t-1} */
+} gic_attn_state;
+
+typedef struct gic_attn_bwd_ws {
+  void* dlogits;                         /* act [B, L, V] */
+  float* dhout;                          /* [B, L, H] */
+  void* dgates;                          /* act [L, B, 4H] */
+  float* dc;                             /* [B, H] */
+  float* dz;                             /* [B, C] */
+  float* dh_extra;                       /* [B, H] */
+  void* dhproj;                          /* act [L, B, A] */
+  float* dfproj;                         /* [B, P, A] */
+  void* dfproj_act;                      /* act [B, P, A] (bf16 mode; may be NULL in f32 mode) */
+  float* dwa_rows;                       /* [B, A] */
+  float* dx;                             /* [L*B, E] */
+} gic_attn_bwd_ws;
+
+int gic_attn_prepare(const gic_attn_dims* dims, const gic_attn_params* params, const gic_attn_shadow* shadow, void* stream);
+/* features f32 [B,E] (the encoder head's output, x_0); fmap act [B,P,C] (the trunk's last feature map, NHWC flattened; no gradient
+ * flows into it: the trunk is frozen, generator.py:21).  noise_u / seed / temperature / pretrain / out / ids as
+ * gic_decoder_sample_fwd.  V % 4 == 0 and E, H, C, A % 8 == 0. */
+int gic_attn_sample_fwd(const gic_attn_dims* dims, const gic_attn_params* params, const gic_attn_shadow* shadow,
+                        const gic_attn_state* state, const float* features, const void* fmap, const float* noise_u, uint64_t seed,
+                        float temperature, int pretrain, void* out, int64_t* ids, void* stream);
+int gic_attn_sample_bwd(const gic_attn_dims* dims, const gic_attn_params* params, const gic_attn_shadow* shadow,
+                        const gic_attn_state* state, const gic_attn_bwd_ws* ws, const void* fmap, const void* probs,
+                        const int64_t* ids, const void* d_out, float temperature, int pretrain, const gic_attn_grads* grads,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Discriminator.forward (src/discriminator.py:34-62) forward + backward.
  */
 typedef struct gic_disc_dims {

@@ -1,0 +1,81 @@
+"""Visual-attention decoder (BASELINE config 4) on the GPU against the build-owned CPU oracle (oracle/cpu_attention.py; NO reference
+counterpart: the roll-out loop it extends, src/generator.py:55-81, is pinned by the goldens).  fp32 parity mode: ids exact,
+probabilities / attention weights rtol 1e-4, every gradient rtol 2e-3 (+1e-4 of the tensor's largest entry); bf16: relative L2."""
+import pytest
+import torch
+
+from oracle import cpu_attention as A
+from tests.gpu_util import close, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["decoder.embed.weight", "decoder.lstm.weight_ih_l0", "decoder.lstm.weight_hh_l0", "decoder.lstm.bias_ih_l0", "decoder.lstm.bias_hh_l0",
+         "decoder.linear.weight", "decoder.linear.bias", "decoder.attn.w_f", "decoder.attn.b_f", "decoder.attn.w_h", "decoder.attn.w_a"]
+
+
+def _problem(B, L, V, E, H, C, P, At, seed, scale=6.0):
+    g = torch.Generator().manual_seed(seed)
+    gp = {k: v * scale for k, v in A.make_attn_params(V, E, H, C, At, g).items()}
+    feats = torch.randn(B, E, generator=g) * 0.3
+    fmap = torch.relu(torch.randn(B, P, C, generator=g))           # post-ReLU trunk activations
+    us = [torch.empty(B, V).uniform_(0, 1, generator=g) for _ in range(L)]
+    d_out = torch.randn(B, L, V, generator=g)
+    return gp, feats, fmap, us, d_out
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 52, 8, 16, 24, 9, 16), (5, 4, 64, 16, 32, 40, 49, 24), (70, 3, 132, 8, 16, 16, 4, 8)])
+def test_attention_decoder_f32_matches_oracle(shape):
+    from gan_image_captioning_amd import engine as E
+    B, L, V, Em, H, C, P, At = shape
+    dev = torch.device("cuda:0")
+    gp, feats, fmap, us, d_out = _problem(*shape, seed=sum(shape))
+    T = 1.4
+    leaf = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    f_leaf = feats.clone().requires_grad_(True)
+    probs, ids_ref, alphas = A.attn_decoder_sample(leaf, f_leaf, fmap, L, T, us)
+    (probs * d_out).sum().backward()
+    eng = E.AttnDecoderEngine(V, Em, H, C, P, At, 0)
+    params = [gp[n].to(dev).contiguous() for n in NAMES]
+    out, ids, st = eng.sample_fwd(params, feats.to(dev), fmap.to(dev), L, T, noise_u=torch.stack(us).to(dev))
+    grads = eng.sample_bwd(params, st, out, ids, d_out.to(dev), T)
+    torch.cuda.synchronize()
+    assert torch.equal(ids.cpu(), ids_ref), "token ids differ from the oracle"
+    close(out, probs, rtol=1e-4, atol_scale=1e-6, what="probs")
+    close(st["alpha"].permute(1, 0, 2), alphas, rtol=1e-4, atol_scale=1e-6, what="attention weights")
+    for n, gt in zip(NAMES, grads[:-1]):
+        close(gt, leaf[n].grad, rtol=2e-3, atol_scale=1e-4, what=n)
+    close(grads[-1], f_leaf.grad, rtol=2e-3, atol_scale=1e-4, what="d_features")
+    # pretrain mode (raw logits, greedy feedback)
+    logits, ids_p, _ = A.attn_decoder_sample(gp, feats, fmap, L, 1.0, None, pretrain=True)
+    outp, idsp, _ = eng.sample_fwd(params, feats.to(dev), fmap.to(dev), L, 1.0, pretrain=True)
+    torch.cuda.synchronize()
+    assert torch.equal(idsp.cpu(), ids_p)
+    close(outp, logits, rtol=1e-4, atol_scale=1e-5, what="pretrain logits")
+
+
+def test_attention_decoder_bf16_at_cfg4_shapes():
+    """BASELINE config 4 per-GPU shapes: B=32, L=20, V=10000, E=H=512, ResNet-50 map 7x7x2048, A=512, bf16: ids match-rate >= 0.9
+    against the fp32 oracle, probabilities and the main gradients (on the GPU's own trajectory) within relative L2 of 5e-2 / 1e-1."""
+    from gan_image_captioning_amd import engine as E
+    shape = (32, 20, 10000, 512, 512, 2048, 49, 512)
+    B, L, V, Em, H, C, P, At = shape
+    dev = torch.device("cuda:0")
+    gp, feats, fmap, us, d_out = _problem(*shape, seed=7, scale=1.0)
+    d_out = d_out * 1e-3
+    T = 1.7
+    eng = E.AttnDecoderEngine(V, Em, H, C, P, At, 1)
+    params = [gp[n].to(dev).contiguous() for n in NAMES]
+    out, ids, st = eng.sample_fwd(params, feats.to(dev), fmap.to(dev), L, T, noise_u=torch.stack(us).to(dev))
+    grads = eng.sample_bwd(params, st, out, ids, d_out.to(dev), T)
+    torch.cuda.synchronize()
+    _, ids_ref, _ = A.attn_decoder_sample(gp, feats, fmap, L, T, us)
+    match = float((ids.cpu() == ids_ref).float().mean())
+    assert match >= 0.9, match
+    leaf = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    probs, _, alphas = A.attn_decoder_sample(leaf, feats, fmap, L, T, us, force_ids=ids.cpu())
+    (probs * d_out).sum().backward()
+    assert rel_l2(out.float(), probs) < 5e-2
+    assert rel_l2(st["alpha"].permute(1, 0, 2), alphas) < 5e-2
+    errs = {n: rel_l2(gt, leaf[n].grad) for n, gt in zip(NAMES, grads[:-1])}
+    print("bf16 attention decoder rel-L2 gradient errors:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs.values()) < 1e-1, errs
