@@ -51,6 +51,11 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-oracle steps per leg (after one warm-up)")
     p.add_argument("--no-prefetch", action="store_true", help="do not hand the next batch's images to the step (no trunk prefetch)")
+    p.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
+                   help="cfg2 (default, the headline: BASELINE configs[1..2], 64 captions/GPU); cfg4: visual-attention decoder, 32 captions/GPU; "
+                        "cfg5: SeqGAN policy gradient + 16 Monte-Carlo roll-outs per prefix, 32 captions/GPU (BASELINE configs[3], [4]: "
+                        "global batch 256 on 8 GPUs)")
+    p.add_argument("--mc-rollouts", type=int, default=16)
     return p.parse_args()
 
 
@@ -65,10 +70,15 @@ def encoder_available() -> bool:
 def build_instructor(a, cgan):
     from gan_image_captioning_amd.args import default_args
     from gan_image_captioning_amd.training import GANInstructor
+    extra = {}
+    if a.workload == "cfg4":
+        extra = dict(decoder="attention", attn_dim=512)
+    elif a.workload == "cfg5":
+        extra = dict(adv_mode="seqgan", mc_rollouts=a.mc_rollouts)
     args = default_args(vocab_size=CFG2["V"], gen_embed_dim=CFG2["E"], gen_hidden_dim=CFG2["H"], gen_num_layers=CFG2["NL"],
                         conditional_gan=cgan, encoder_arch=a.encoder, compute_dtype=a.dtype, step_impl=a.step_impl,
                         adv_train_batch_size=a.batch, image_size=CFG2["S"], device="cuda", log_file=None, model_dir=None,
-                        save_dir=None)
+                        save_dir=None, **extra)
     torch.manual_seed(1008)                      # src/main.py:14
     inst = GANInstructor(args, None, None)
     inst.gen.train()
@@ -224,6 +234,8 @@ def self_launch(a) -> int:
 
 def main():
     a = parse()
+    if a.workload != "cfg2" and a.batch == CFG2["B"]:
+        a.batch = 32                           # BASELINE configs[3], [4]: global batch 256 over 8 GPUs
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         raise SystemExit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -274,8 +286,10 @@ def main():
         "metric": "captions/sec (G+D train step)", "value": round(value, 2), "unit": "captions/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": "cfg2: adversarial G+D step, batch %d/GPU, 224x224 images, caption len 20, V=10000, E=H=512, "
+        "config": {"workload": "%s: adversarial G+D step%s, batch %d/GPU, 224x224 images, caption len 20, V=10000, E=H=512, "
                                "1-layer LSTM G, CNN-seq D (R=64,F=900), %s" % (
+                                   a.workload, {"cfg2": "", "cfg4": " with the visual-attention decoder (7x7 map, A=512)",
+                                                "cfg5": " SeqGAN-style (policy gradient, %d Monte-Carlo roll-outs per prefix)" % a.mc_rollouts}[a.workload],
                                    a.batch, ("ResNet-50-shaped" if a.encoder == "resnet50" else "ResNet-18-shaped") + " encoder, --conditional-gan 1"
                                    if cgan else "--conditional-gan 0 (no encoder in the step)"),
                    "global_batch": world * a.batch, "caption_len": CFG2["L"], "image_size": CFG2["S"], "vocab": CFG2["V"],
@@ -283,8 +297,8 @@ def main():
                    "parallelism": "dp%d" % world},
     }
     log(f"timed region done: {elapsed / a.steps * 1e3:.3f} ms/step; roofline probe")
-    out["roofline"] = roofline_probe(inst, args, cgan, step)
-    if world == 1 and not a.no_cpu_baseline:
+    out["roofline"] = roofline_probe(inst, args, cgan, step if a.workload != "cfg4" else None)
+    if world == 1 and not a.no_cpu_baseline and a.workload == "cfg2":
         out["cpu_baseline"] = cpu_baseline(a, cgan)
     print(json.dumps(out), flush=True)
 

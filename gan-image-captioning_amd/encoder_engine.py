@@ -266,6 +266,10 @@ class TrunkPlan:
             self.pending_tracked += 1          # num_batches_tracked buffers are brought up to date by sync_counters()
         return b["feat"]
 
+    def last_map(self, N: int, S: int) -> torch.Tensor:
+        """The last block's output [N, h, w, C] of the most recent pass at this shape (the plan's live buffer: clone to keep)."""
+        return self._bufs[(N, S)]["blocks"][-1]["out"]
+
     def _launch_trunk(self, b: dict, N: int, S: int, training: bool) -> None:
         """Everything behind the packed image runs on the plan's own buffers with fixed arguments: ~105 launches that
         are replayed as ONE hipGraph (the second call with a given key captures it; GIC_NO_GRAPH=1 keeps eager launches).

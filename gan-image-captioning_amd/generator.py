@@ -178,6 +178,78 @@ class Decoder(nn.Module):
         return o_t + (-torch.log(-torch.log(u + eps) + eps))
 
 
+# ------------------------------------------------------------------------------------------ visual-attention decoder
+class _AttnSampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, temperature, pretrain, max_len, noise_u, seed, fmap, features, *params):
+        dparams = [p.detach() for p in params]
+        out, ids, st = eng.sample_fwd(dparams, features.detach().float(), fmap.detach(), max_len, temperature, pretrain, noise_u, seed)
+        ctx.eng, ctx.temperature, ctx.pretrain, ctx.st, ctx.dparams = eng, temperature, pretrain, st, dparams
+        ctx.save_for_backward(out, ids)
+        ctx.mark_non_differentiable(ids)
+        return out, ids
+
+    @staticmethod
+    def backward(ctx, d_out, _d_ids):
+        out, ids = ctx.saved_tensors
+        grads = ctx.eng.sample_bwd(ctx.dparams, ctx.st, out, ids, d_out, ctx.temperature, ctx.pretrain)
+        ctx.st = None
+        return (None, None, None, None, None, None, None, grads[-1], *grads[:-1])
+
+
+class _AttnParams(nn.Module):
+    """Additive (Show-Attend-Tell) attention parameters: e_i = w_a . tanh(W_f a_i + b_f + W_h h)."""
+
+    def __init__(self, feat_c: int, hidden: int, attn: int):
+        super().__init__()
+        k = 1.0 / math.sqrt(attn)
+        self.w_f = nn.Parameter(torch.empty(attn, feat_c).uniform_(-k, k))
+        self.b_f = nn.Parameter(torch.zeros(attn))
+        self.w_h = nn.Parameter(torch.empty(attn, hidden).uniform_(-k, k))
+        self.w_a = nn.Parameter(torch.empty(attn).uniform_(-k, k))
+
+
+class AttnDecoder(nn.Module):
+    """Caption decoder with soft visual attention over the trunk's feature map (``--decoder attention``, BASELINE config 4).  NO
+    reference counterpart: the reference's Decoder (generator.py:27-96) with a context vector z_t = sum_i alpha_ti a_i concatenated
+    to the LSTM input (oracle/cpu_attention.py).  One LSTM layer; same ``embed`` / ``lstm`` / ``linear`` state-dict keys as the
+    reference's Decoder plus ``attn.*``; ``sample`` takes the feature map next to the start features."""
+
+    def __init__(self, args, feat_c: int, positions: int):
+        super().__init__()
+        if args.gen_num_layers != 1:
+            raise ValueError("--decoder attention supports one LSTM layer")
+        self.embed = Embedding(args.vocab_size, args.gen_embed_dim)
+        self.lstm = _LSTMParams(args.gen_embed_dim + feat_c, args.gen_hidden_dim, 1)
+        self.linear = _LinearParams(args.gen_hidden_dim, args.vocab_size)
+        self.attn = _AttnParams(feat_c, args.gen_hidden_dim, int(getattr(args, "attn_dim", 512)))
+        self.max_seq_length = args.max_seq_len
+        self.temperature = args.temperature
+        self.args, self.feat_c, self.positions = args, feat_c, positions
+        self._engine = None
+
+    def engine(self):
+        if self._engine is None:
+            a = self.args
+            self._engine = engine.AttnDecoderEngine(a.vocab_size, a.gen_embed_dim, a.gen_hidden_dim, self.feat_c, self.positions,
+                                                    self.attn.w_a.numel(), _compute_dtype(a))
+        return self._engine
+
+    def param_list(self) -> List[nn.Parameter]:
+        return [self.embed.weight] + self.lstm.layer_params(0) + [self.linear.weight, self.linear.bias, self.attn.w_f, self.attn.b_f,
+                                                                   self.attn.w_h, self.attn.w_a]
+
+    def sample(self, features, fmap=None, states=None, pretrain=False, max_caption_len=34, noise_u=None):
+        """(outputs [B,L,V], ids [B,L]) as Decoder.sample; ``fmap`` [B, P, C]: the trunk's last feature map (no gradient into it)."""
+        if fmap is None:
+            raise ValueError("the attention decoder needs the trunk's feature map: sample(features, fmap)")
+        if states is not None:
+            raise NotImplementedError("the attention decoder starts from zero states")
+        seed = 0 if noise_u is not None else SEEDS.next()
+        return _AttnSampleFn.apply(self.engine(), float(self.temperature), bool(pretrain), int(max_caption_len), noise_u, seed, fmap,
+                                   features, *self.param_list())
+
+
 # ------------------------------------------------------------------------------------------ encoder
 class _EncoderHeadFn(torch.autograd.Function):
     @staticmethod
@@ -229,6 +301,25 @@ class Encoder(nn.Module):
         return _EncoderHeadFn.apply(_compute_dtype(self.args), self.training, self.bn.momentum, self.bn.eps, feats,
                                     self.linear.weight, self.linear.bias, self.bn.weight, self.bn.bias,
                                     self.bn.running_mean, self.bn.running_var)
+
+    def forward_with_map(self, images):
+        """(features [B,E] as forward(), feature map [B, P, C] = the trunk's last activation, detached) for the attention decoder."""
+        with torch.no_grad():
+            main = torch.cuda.current_stream(images.device)
+            pre, self._pre = getattr(self, "_pre", None), None
+            if pre is not None:
+                main.wait_event(pre[3])             # an unused look-ahead pass on the shared plan buffers
+            busy = getattr(self, "_busy", None)
+            if busy is not None:
+                main.wait_event(busy)
+            feats = self.trunk_features(images, self.training).clone()      # always a pass here: the map is the plan's live buffer
+            fmap = self.resnet._plan.last_map(images.shape[0], images.shape[2]).clone()
+            self._busy = main.record_event()
+        feats = feats.reshape(feats.size(0), -1)
+        out = _EncoderHeadFn.apply(_compute_dtype(self.args), self.training, self.bn.momentum, self.bn.eps, feats,
+                                   self.linear.weight, self.linear.bias, self.bn.weight, self.bn.bias,
+                                   self.bn.running_mean, self.bn.running_var)
+        return out, fmap.view(fmap.shape[0], -1, fmap.shape[-1])
 
     # ---- trunk look-ahead: the trunk is frozen (generator.py:21), so the pass for the NEXT batch depends on nothing the current
     # step updates; it runs on its own stream under the step's launch-bound phases and hands over a private copy of its output.
@@ -294,7 +385,13 @@ class Generator(nn.Module):
     def __init__(self, args):
         super().__init__()
         self.encoder = Encoder(args)
-        self.decoder = Decoder(args)
+        if getattr(args, "decoder", "lstm") == "attention":
+            if int(args.conditional_gan) != 1:
+                raise ValueError("--decoder attention attends over image features: it needs --conditional-gan 1")
+            side = int(getattr(args, "image_size", 224)) // 32
+            self.decoder = AttnDecoder(args, self.encoder.resnet.out_features, side * side)
+        else:
+            self.decoder = Decoder(args)
         self.args = args
         self.init_params()
 

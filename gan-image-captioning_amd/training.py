@@ -83,6 +83,11 @@ class GANInstructor:
         self.gen = Generator(args).to(args.device)                        # training.py:19
         self.disc = Discriminator(args).to(args.device)                   # training.py:20
         self.cgan = (args.conditional_gan == 1)
+        self.attention = getattr(args, "decoder", "lstm") == "attention"
+        if self.attention:
+            if getattr(args, "adv_mode", "relgan") != "relgan":
+                raise ValueError("--decoder attention is trained with the relaxation (--adv-mode relgan)")
+            args.step_impl = "autograd"        # the attention decoder runs through the module API (autograd.Function wrappers)
         if self.dist.world_size > 1:
             parallel.broadcast_module(self.gen, self.dist)
             parallel.broadcast_module(self.disc, self.dist)
@@ -130,6 +135,8 @@ class GANInstructor:
 
     # ------------------------------------------------------------------ shared pieces
     def _features(self, images, batch, next_images=None):
+        if self.attention:
+            return self.gen.encoder.forward_with_map(images)               # (features, feature map)
         if self.cgan:
             return self.gen.encoder(images, next_images=next_images)       # training.py:66,145
         ones = torch.ones(batch, dtype=torch.long, device=self.args.device)
@@ -156,7 +163,10 @@ class GANInstructor:
     # ------------------------------------------------------------------ MLE pre-training (training.py:48-126)
     def pretrain_step(self, images, captions, max_caption_len, train=True, next_images=None):
         feats = self._features(images, captions.shape[0], next_images)
-        gen_captions, _ids = self.gen.decoder.sample(feats, pretrain=True, max_caption_len=max_caption_len)
+        if self.attention:
+            gen_captions, _ids = self.gen.decoder.sample(feats[0], fmap=feats[1], pretrain=True, max_caption_len=max_caption_len)
+        else:
+            gen_captions, _ids = self.gen.decoder.sample(feats, pretrain=True, max_caption_len=max_caption_len)
         flat = gen_captions.reshape(-1, gen_captions.size(-1))
         loss = _XentFn.apply(flat, captions.reshape(-1))                   # nn.CrossEntropyLoss(), training.py:81-83
         if train:
@@ -218,7 +228,10 @@ class GANInstructor:
         km = keep_masks if keep_masks is not None else (None, None, None)
         with (torch.enable_grad() if train else torch.no_grad()):
             features = self._features(images, captions.shape[0])
-            gen_captions, _ids = self.gen.decoder.sample(features, max_caption_len=max_caption_len, noise_u=noise_u)
+            if self.attention:
+                gen_captions, _ids = self.gen.decoder.sample(features[0], fmap=features[1], max_caption_len=max_caption_len, noise_u=noise_u)
+            else:
+                gen_captions, _ids = self.gen.decoder.sample(features, max_caption_len=max_caption_len, noise_u=noise_u)
             fake_captions = gen_captions.detach()                                            # training.py:151
             if int(getattr(self.args, "real_as_ids", 1)):
                 real = captions

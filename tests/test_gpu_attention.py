@@ -79,3 +79,43 @@ def test_attention_decoder_bf16_at_cfg4_shapes():
     errs = {n: rel_l2(gt, leaf[n].grad) for n, gt in zip(NAMES, grads[:-1])}
     print("bf16 attention decoder rel-L2 gradient errors:", {k: f"{v:.1e}" for k, v in errs.items()})
     assert max(errs.values()) < 1e-1, errs
+
+
+def test_attention_adversarial_and_pretrain_steps_through_the_instructor():
+    """--decoder attention end to end (module API path): ResNet-18 trunk at 64x64 (2x2x512 map), one adversarial step and one MLE
+    pre-train step: finite losses, generator (incl. attention parameters) and discriminator updated; the decoder's forward agrees
+    with the oracle on the instructor's own weights and feature map."""
+    from gan_image_captioning_amd.args import default_args
+    from gan_image_captioning_amd.training import GANInstructor
+    from oracle import cpu_step as O
+    B, L, V = 8, 6, 64
+    args = default_args(vocab_size=V, gen_embed_dim=16, gen_hidden_dim=32, conditional_gan=1, encoder_arch="resnet18", decoder="attention",
+                        attn_dim=24, compute_dtype="fp32", image_size=64, device="cuda", log_file=None, model_dir=None, save_dir=None)
+    inst = GANInstructor(args, None, None)
+    dev = args.device
+    assert args.step_impl == "autograd"
+    g = torch.Generator().manual_seed(3)
+    images = torch.randn(B, 3, 64, 64, generator=g).to(dev)
+    caps = O.make_captions(B, L, V, g).to(dev)
+    inst.gen.train(); inst.disc.train()
+    with torch.no_grad():
+        for p in inst.gen.decoder.parameters():
+            p.mul_(8.0)                                      # away from the near-uniform init
+    # decoder forward vs the oracle on the same weights / features / map
+    feats, fmap = inst.gen.encoder.forward_with_map(images)
+    us = [torch.empty(B, V).uniform_(0, 1, generator=g) for _ in range(L)]
+    inst.gen.decoder.temperature = 1.3
+    probs, ids = inst.gen.decoder.sample(feats, fmap=fmap, max_caption_len=L, noise_u=torch.stack(us).to(dev))
+    torch.cuda.synchronize()
+    gp = {"decoder." + k: v.detach().cpu() for k, v in inst.gen.decoder.state_dict().items()}
+    want, ids_ref, _ = A.attn_decoder_sample(gp, feats.detach().cpu(), fmap.float().cpu(), L, 1.3, us)
+    assert torch.equal(ids.cpu(), ids_ref)
+    close(probs, want, rtol=1e-4, atol_scale=1e-6, what="probs through the module API")
+    before = inst.gen_arena.flat.clone(), inst.disc_arena.flat.clone()
+    attn_before = inst.gen.decoder.attn.w_f.detach().clone()
+    losses = inst.adv_step(images, caps, L, train=True)
+    loss_p = inst.pretrain_step(images, caps, L, train=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(losses).all() and torch.isfinite(loss_p).all()
+    assert not torch.equal(before[0], inst.gen_arena.flat) and not torch.equal(before[1], inst.disc_arena.flat)
+    assert not torch.equal(attn_before, inst.gen.decoder.attn.w_f.detach())
