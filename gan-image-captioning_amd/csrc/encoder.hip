@@ -382,6 +382,28 @@ int gic_conv2d_bn_in(const void* in, const float* in_stats, int in_nrep, const f
   return gemm(g, (hipStream_t)stream);
 }
 
+int gic_conv1x1_res_in(const void* in, const float* in_stats, int in_nrep, const float* in_gamma, const float* in_beta, const void* res,
+                       const float* res_stats, int res_nrep, const float* res_gamma, const float* res_beta, float count, void* block_out,
+                       const void* w, void* out, float* stats, int stats_nrep, int dtype, int N, int H, int W, int Cin, int Cout, void* stream) {
+  GIC_CHECK_ARG(in && in_stats && in_gamma && in_beta && res && block_out && w && out && stats && count > 0 && in_nrep >= 1, "conv1x1_res_in: bad argument");
+  GIC_CHECK_ARG(!res_stats || (res_gamma && res_beta && res_nrep >= 1), "conv1x1_res_in: the shortcut's BatchNorm needs gamma and beta");
+  GIC_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv1x1_res_in: bad dims");
+  if (dtype != DT_BF16) return GIC_ERR_UNSUPPORTED;
+  GemmDesc g;
+  g.A = in; g.B = w; g.C = out;
+  g.M = N * H * W; g.N = Cout; g.K = Cin;
+  g.lda = Cin; g.ldb = g.K; g.ldc = Cout;
+  g.in_dtype = dtype; g.out_dtype = dtype;
+  g.conv = 1; g.cH = H; g.cW = W; g.cCin = Cin; g.cHo = H; g.cWo = W; g.cKH = 1; g.cKW = 1; g.cStride = 1; g.cPad = 0;
+  g.epi = EPI_BNSTATS;
+  g.stats = stats;
+  g.stats_nrep = stats_nrep < 1 ? 1 : stats_nrep;
+  g.in_stats = in_stats; g.in_nrep = in_nrep; g.in_gamma = in_gamma; g.in_beta = in_beta; g.in_inv_count = 1.f / count;
+  g.res = res; g.res_stats = res_stats; g.res_nrep = res_nrep; g.res_gamma = res_gamma; g.res_beta = res_beta; g.res_inv_count = 1.f / count;
+  g.out_wb = block_out;
+  return gemm(g, (hipStream_t)stream);
+}
+
 int gic_bn_act(const void* y, const float* stats, const float* gamma, const float* beta, const float* run_mean, const float* run_var,
                const void* res, const float* res_stats, const float* res_gamma, const float* res_beta, const float* res_run_mean,
                const float* res_run_var, int stats_nrep, float count, int relu, void* out, int dtype, int64_t rows, int C, void* stream) {

@@ -51,6 +51,15 @@ struct GemmDesc {
   const float* in_stats = nullptr; int in_nrep = 1;
   const float* in_gamma = nullptr; const float* in_beta = nullptr;
   float in_inv_count = 0.f;
+  // ---- ... + residual (the block output of a ResNet bottleneck formed on load; 1x1 / stride 1 / pad 0 consumers only): the operand is
+  //      relu(scale*x + shift + r) with r = res[m, c] as is (identity shortcut) or res_scale*res + res_shift from res_stats / res_gamma /
+  //      res_beta (projection shortcut, its own BatchNorm).  Workgroups of the first N tile also WRITE the formed tile to out_wb
+  //      [M, Cin] (the block output, needed again as the next shortcut): the separate bn + add + relu pass disappears.
+  const void* res = nullptr;
+  const float* res_stats = nullptr; int res_nrep = 1;
+  const float* res_gamma = nullptr; const float* res_beta = nullptr;
+  float res_inv_count = 0.f;
+  void* out_wb = nullptr;
   int dbg = 0;              // phase-ablation knob, honoured only by -DGIC_STAMPS tool builds
 };
 

@@ -526,18 +526,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
 //     zero without touching memory -- no 64-bit address math, no branches, no zero page;
 //   * every iteration issues exactly NL DMAs, so the counted s_waitcnt is a constant and the loop body is branch-free.
 // Waves are 4 (M) x 2 (N): a wave owns 32 x BN/2 of the tile.  LDS image, swizzle and C/D layout as in the kernel above.
-template <typename TO, int BN, int EPI, bool CONV, int NS, bool ABN = false>
+template <typename TO, int BN, int EPI, bool CONV, int NS, bool ABN = false, bool ARES = false>
 __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsigned a_bytes, const unsigned b_bytes) {
+  static_assert(!ARES || ABN, "the residual-on-load form extends the A-side BatchNorm");
   constexpr int BM = 128, BK = 64, NT = 512;
   constexpr int TM = 2, TN = BN / 32;
   constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;          // 16-B chunks per thread per tile
-  constexpr int NL = CA + CB;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int NL = CA + CB + (ARES ? CA : 0);              // LDS-DMA instructions per thread per stage
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, R_BYTES = ARES ? A_BYTES : 0, STAGE = A_BYTES + B_BYTES + R_BYTES;
   constexpr int OSZ = sizeof(TO), OVE = 16 / OSZ, SC = BN * OSZ + 16;
   constexpr int EPI_BYTES = EPI == EPI_HIGHWAY ? BM * (BN + 4) * 4 : BM * SC + 8 * (BN / 2) * 2 * 4;   // highway stages h in f32
   constexpr int RING_BYTES = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
-  constexpr int ABN_MAXK = 1024;                              // A-side BatchNorm: [scale, shift] per input channel behind the ring
-  constexpr int SMEM_BYTES = RING_BYTES + (ABN ? ABN_MAXK * 8 : 0);
+  constexpr int ABN_MAXK = ARES ? 2048 : 1024;                // A-side BatchNorm: [scale, shift] per input channel behind the ring
+  constexpr int SMEM_BYTES = RING_BYTES + (ABN ? ABN_MAXK * 8 : 0) + (ARES ? ABN_MAXK * 8 : 0);     // ARES: + the shortcut's [scale, shift]
   constexpr unsigned OOB = 0x80000000u;                       // >= any extent this kernel is launched with
   static_assert(CB >= 1 && SMEM_BYTES <= 160 * 1024, "tile8 LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
@@ -559,6 +560,7 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
 
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)d.B, 0, (int)b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(ARES ? d.res : d.A), 0, (int)a_bytes, 0x00020000);
 
   // ---- per-thread chunk coordinates: rows (tid>>3) + 64 i, physical chunk slot tid&7 = logical chunk ^ swizzle(row)
   const int kc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;           // logical k offset (elements) inside a K tile
@@ -613,6 +615,8 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
         voff = (a_ok[i] & kok) ? (unsigned)(a_off[i] + k) * 2u : OOB;
       }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(sA + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, 0);
+      if constexpr (ARES)        // the shortcut tile: same rows and channels of `res`, behind the B tile of the stage
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsR, (lds_void_ptr)(sB + B_BYTES + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
@@ -644,9 +648,22 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
         sh = d.in_beta[c] - mean * sc;
       }
       coef[2 * c] = sc; coef[2 * c + 1] = sh;
+      if constexpr (ARES) {      // the shortcut: its own BatchNorm (projection) or identity (scale 1, shift 0)
+        float rs = 1.f, rt = 0.f;
+        if (d.res_stats && c < Cn) {
+          float s1 = 0.f, s2 = 0.f;
+          for (int r = 0; r < d.res_nrep; ++r) { s1 += d.res_stats[(long)r * 2 * Cn + c]; s2 += d.res_stats[(long)r * 2 * Cn + Cn + c]; }
+          const float mean = s1 * d.res_inv_count;
+          const float var = fmaxf(s2 * d.res_inv_count - mean * mean, 0.f);
+          rs = d.res_gamma[c] * rsqrtf(var + 1e-5f);
+          rt = d.res_beta[c] - mean * rs;
+        }
+        coef[2 * ABN_MAXK + 2 * c] = rs; coef[2 * ABN_MAXK + 2 * c + 1] = rt;
+      }
     }
     __syncthreads();
   }
+  const bool wb = ARES && d.out_wb && bn0 == 0;              // first N tile: also materialise the formed operand (the block output)
   auto abn = [&](int kt, int st) {
     if constexpr (ABN) {
       const int k = kt * BK + kc;
@@ -659,6 +676,13 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
         const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
         const float scl[8] = {c0.x, c0.z, c1.x, c1.z, c2.x, c2.z, c3.x, c3.z};
         const float sft[8] = {c0.y, c0.w, c1.y, c1.w, c2.y, c2.w, c3.y, c3.w};
+        float rsc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, rsf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (ARES) {
+          const float4* rp = (const float4*)(coef + 2 * ABN_MAXK + 2 * ch);
+          const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+          rsc[0] = r0.x; rsc[1] = r0.z; rsc[2] = r1.x; rsc[3] = r1.z; rsc[4] = r2.x; rsc[5] = r2.z; rsc[6] = r3.x; rsc[7] = r3.z;
+          rsf[0] = r0.y; rsf[1] = r0.w; rsf[2] = r1.y; rsf[3] = r1.w; rsf[4] = r2.y; rsf[5] = r2.w; rsf[6] = r3.y; rsf[7] = r3.w;
+        }
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
           // padding taps and rows past M were zero-filled by the DMA and stay zero (the reference pads the NORMALISED tensor)
@@ -666,8 +690,16 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
           if (!ok) continue;
           bf16x8* p = (bf16x8*)(smem + st * STAGE + i * (NT * 16) + tid * 16);
           bf16x8 v = *p;
+          if constexpr (ARES) {
+            const bf16x8 r = *(const bf16x8*)(smem + st * STAGE + A_BYTES + B_BYTES + i * (NT * 16) + tid * 16);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (bf16_t)fmaxf((float)v[e] * scl[e] + sft[e], 0.f);
+            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)fmaxf((float)v[e] * scl[e] + sft[e] + ((float)r[e] * rsc[e] + rsf[e]), 0.f);
+            // 1x1 / stride 1 / pad 0: operand row m, channels k..k+7 = element a_off[i] + k of the [M, Cin] block output
+            if (wb) *(bf16x8*)((bf16_t*)d.out_wb + (long)a_off[i] + k) = v;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)fmaxf((float)v[e] * scl[e] + sft[e], 0.f);
+          }
           *p = v;
         }
       }
@@ -984,6 +1016,17 @@ bool try_tile8(const GemmDesc& d, hipStream_t stream) {
   // deep ring (4 stages, 128 KB: one block per CU) when the grid is about one block per CU; with several blocks per CU a
   // 2-stage ring (64 KB) lets two blocks share the CU so one block's epilogue runs under the other's K loop
   if constexpr (EPI == EPI_BNSTATS && CONV) {
+    if (d.in_stats && d.res) {      // + residual on load: 1x1 / stride 1 / pad 0 only, one- or two-stage ring (two tiles per stage on the A side)
+      if (d.cKH != 1 || d.cKW != 1 || d.cStride != 1 || d.cPad != 0 || d.cCin % 8 || d.cCin > 2048 || !d.in_gamma || !d.in_beta ||
+          d.in_inv_count <= 0.f || (d.res_stats && (!d.res_gamma || !d.res_beta || d.res_inv_count <= 0.f)))
+        return false;
+      const bool n128 = d.N >= 128;
+      const long tiles = n128 ? big_tiles : (long)cdiv(d.M, 128) * cdiv(d.N, 64);
+      const dim3 grid((unsigned)tiles), block(512);
+      if (n128) hipLaunchKernelGGL((tile8_kernel<TO, 128, EPI, CONV, 2, true, true>), grid, block, 0, stream, d, ab, bb);
+      else hipLaunchKernelGGL((tile8_kernel<TO, 64, EPI, CONV, 2, true, true>), grid, block, 0, stream, d, ab, bb);
+      return true;
+    }
     if (d.in_stats) {      // A-side BatchNorm + ReLU: whole 16-byte chunks per tap, channels within the LDS table
       if (d.cCin % 8 || d.cCin > 1024 || !d.in_gamma || !d.in_beta || d.in_inv_count <= 0.f) return false;
       const int nk = cdiv(d.K, 64);

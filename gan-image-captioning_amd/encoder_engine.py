@@ -93,6 +93,7 @@ class TrunkPlan:
         self._graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
         self._warm: set = set()
         self.fuse_in = not os.environ.get("GIC_NO_FUSED_BN_IN")
+        self.fuse_res = not os.environ.get("GIC_NO_FUSED_RES_IN")        # block outputs formed on load by the next conv1 (gic_conv1x1_res_in)
         self._nrep = {}
         self.use_graph = not os.environ.get("GIC_NO_GRAPH")
         self.pending_tracked = 0
@@ -232,6 +233,30 @@ class TrunkPlan:
         self._bn_act(prev, y_prev, z_prev, stats, training, rows_prev)
         self._conv(s, z_prev, y, stats, N, H, W)
 
+    def _conv1_res_in(self, pend, c1: _ConvStep, y1, stats, N, H, W) -> bool:
+        """conv1 of a block whose input (the previous block's output) is still pending: formed on load and written to its buffer by
+        the convolution itself.  pend = (last step, its raw output, shortcut tensor, shortcut step | None, rows, out buffer)."""
+        last, ylast, res, res_step, rows, out = pend
+        if c1.fused_in is False or c1.k != 1 or c1.stride != 1:
+            return False
+        base = stats.data_ptr()
+        rs = base + 4 * res_step.stats_off if res_step is not None else None
+        with self._traced(c1.name):
+            status = L.load().gic_conv1x1_res_in(
+                ptr(ylast), base + 4 * last.stats_off, self._nrep[last.name], ptr(last.bn.weight.detach()), ptr(last.bn.bias.detach()),
+                ptr(res), rs, self._nrep[res_step.name] if res_step is not None else 1,
+                ptr(res_step.bn.weight.detach()) if res_step is not None else None, ptr(res_step.bn.bias.detach()) if res_step is not None else None,
+                float(rows), ptr(out), ptr(c1.w), ptr(y1), base + 4 * c1.stats_off, self._nrep[c1.name], self.dtype, N, H, W, c1.cin, c1.cout,
+                stream_ptr())
+        if status == L.ERR_UNSUPPORTED:
+            if self.conv_trace:
+                self.conv_trace.pop()
+            c1.fused_in = False
+            return False
+        _check(status, "gic_conv1x1_res_in " + c1.name)
+        c1.fused_in = True
+        return True
+
     def _bn_args(self, s: Optional[_ConvStep], stats: Optional[torch.Tensor], training: bool):
         """(stats, gamma, beta, run_mean, run_var) pointers of one BatchNorm; all None for 'no BN'."""
         if s is None:
@@ -312,16 +337,32 @@ class TrunkPlan:
         _check(lib.gic_bn_relu_maxpool(ptr(b["y0"]), *a, self._nrep[self.stem.name], float(rows[self.stem.name]), ptr(b["x0"]), self.dtype, N, h, h, 64, stream_ptr()),
                "gic_bn_relu_maxpool")
         x = b["x0"]
+        pend = None     # a block output not yet materialised: (last step, raw output, shortcut, shortcut step | None, rows, out buffer)
+        fuse_res = training and self.fuse_res and self.dtype != L.F32
+
+        def flush():
+            nonlocal pend
+            if pend is not None:
+                last, ylast, res, res_step, rows_, out = pend
+                self._bn_act(last, ylast, out, stats, training, rows_, res=res, res_step=res_step)
+                pend = None
+
         for blk, e in zip(self.blocks, b["blocks"]):
             c1, c2, c3, ds = blk["c1"], blk["c2"], blk["c3"], blk["ds"]
             hin, ho = e["hin"], e["hout"]
             if blk["kind"] == "basic":
+                flush()
                 self._conv(c1, x, e["y1"], stats, N, hin, hin)
                 self._bn_act(c1, e["y1"], e["z1"], stats, training, rows[c1.name])
                 self._conv(c2, e["z1"], e["y2"], stats, N, ho, ho)
                 last, ylast = c2, e["y2"]
             else:
-                self._conv(c1, x, e["y1"], stats, N, hin, hin)
+                # conv1: if the previous block's output is pending, it is formed on load (bn3 + shortcut + relu) and written by the
+                # convolution's first N tile; otherwise a plain convolution on the materialised input
+                if pend is None or not self._conv1_res_in(pend, c1, e["y1"], stats, N, hin, hin):
+                    flush()
+                    self._conv(c1, x, e["y1"], stats, N, hin, hin)
+                pend = None
                 # measured: riding bn1 into the 3x3 convolution's A path costs more than the bn_act it saves (the tile is rewritten
                 # once per tap); the 1x1 consumer below is where it pays
                 self._bn_act(c1, e["y1"], e["z1"], stats, training, rows[c1.name])
@@ -329,11 +370,16 @@ class TrunkPlan:
                 self._bn_relu_conv(c2, e["y2"], e["z2"], c3, e["y3"], stats, training, N, ho, ho, rows[c2.name])
                 last, ylast = c3, e["y3"]
             if ds is not None:
-                self._conv(ds, x, e["yd"], stats, N, hin, hin)
-                self._bn_act(last, ylast, e["out"], stats, training, rows[last.name], res=e["yd"], res_step=ds)
+                self._conv(ds, x, e["yd"], stats, N, hin, hin)        # reads the (by now materialised) block input
+                res, res_step = e["yd"], ds
             else:
-                self._bn_act(last, ylast, e["out"], stats, training, rows[last.name], res=x, res_step=None)
+                res, res_step = x, None
+            if fuse_res and blk["kind"] != "basic":
+                pend = (last, ylast, res, res_step, rows[last.name], e["out"])
+            else:
+                self._bn_act(last, ylast, e["out"], stats, training, rows[last.name], res=res, res_step=res_step)
             x = e["out"]
+        flush()                                                        # the last block's output feeds the average pool
         ho = x.shape[1]
         _check(lib.gic_avgpool(ptr(x), ptr(b["feat"]), self.dtype, N, ho * ho, x.shape[3], stream_ptr()), "gic_avgpool")
         if training:
@@ -342,8 +388,13 @@ class TrunkPlan:
     # ---------------------------------------------------------------- measurement helper for bench.py
     def replay(self, s: _ConvStep, xi, yo, stats, N: int, H: int, W: int, kw: dict, prev=None) -> None:
         """One launch of the step's convolution for layer `s` as the training forward issues it (measurement helper): the
-        A-side-BatchNorm variant where the plan uses it (prev = (producer step, its raw output, its row count)), else gic_conv2d."""
-        if prev is not None and s.fused_in:
+        A-side-BatchNorm variant where the plan uses it (prev = (producer step, its raw output, its row count)), the residual-on-load
+        variant (prev = ("res", pending tuple)), else gic_conv2d."""
+        if prev is not None and prev[0] == "res":
+            if s.fused_in and self._conv1_res_in(prev[1], s, yo, stats, N, H, W):
+                return
+            self._conv(s, xi, yo, stats, N, H, W, **kw)
+        elif prev is not None and s.fused_in:
             p, yp, rows_p = prev
             self._bn_relu_conv(p, yp, None, s, yo, stats, True, N, H, W, rows_p)
         else:
@@ -351,14 +402,16 @@ class TrunkPlan:
 
     def conv_shapes(self, N: int, S: int):
         """[(step, input tensor, output tensor, H, W, conv kwargs, macs, prev)] in execution order; prev = (producer step, its raw
-        output, its rows) for the layers whose input BatchNorm can ride in the convolution."""
+        output, its rows) for the layers whose input BatchNorm rides in the convolution, ("res", pending tuple) for a conv1 that
+        forms the previous block's output on load."""
         b = self._buffers(N, S, self.stem.conv.weight.device)
         out = [(self.stem, b["xin"], b["y0"], S + 6, S + 6, dict(cin=4, kw=8, pad=0), b["y0"].shape[1] ** 2 * N * 64 * 147, None)]
         x = b["x0"]
+        pend = None
         for blk, e in zip(self.blocks, b["blocks"]):
             c1, c2, c3, ds = blk["c1"], blk["c2"], blk["c3"], blk["ds"]
             hin, ho = e["hin"], e["hout"]
-            seq = [(c1, x, e["y1"], hin, None),
+            seq = [(c1, x, e["y1"], hin, ("res", pend) if (pend is not None and c1.fused_in) else None),
                    (c2, e["z1"], e["y2"], ho if blk["kind"] == "basic" else hin, None)]
             if c3 is not None:
                 seq.append((c3, e["z2"], e["y3"], ho, (c2, e["y2"], b["rows"][c2.name])))
@@ -366,6 +419,9 @@ class TrunkPlan:
                 seq.append((ds, x, e["yd"], hin, None))
             for s, xi, yo, hh, prev in seq:
                 out.append((s, xi, yo, hh, hh, {}, yo.shape[0] * yo.shape[1] * yo.shape[2] * s.cout * s.cin * s.k * s.k, prev))
+            if blk["kind"] != "basic":
+                last = c3
+                pend = (last, e["y3"], e["yd"] if ds is not None else x, ds, b["rows"][last.name], e["out"])
             x = e["out"]
         return out
 
@@ -436,10 +492,11 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None, 
     seen = {}
     per_layer_step_ms = {}
     for s, xi, yo, H, W, kw, macs, prev in plan.conv_shapes(N, S):
-        key = (s.cin, s.cout, s.k, s.stride, H, bool(prev is not None and s.fused_in))
+        mode = 0 if (prev is None or not s.fused_in) else (2 if prev[0] == "res" else 1)
+        key = (s.cin, s.cout, s.k, s.stride, H, mode + (10 if (mode == 2 and prev[1][3] is not None) else 0))
         if key not in seen:
             seen[key] = [event_time_ms(lambda: plan.replay(s, xi, yo, b["stats"], N, H, W, kw, prev), 5, stream), 0, macs,
-                         s.name + (" [bn+relu on load]" if key[5] else ""), 0.0]
+                         s.name + {0: "", 1: " [bn+relu on load]", 2: " [block output on load]", 12: " [block output on load, proj.]"}[key[5]], 0.0]
         seen[key][1] += 1
         if in_step and s.name in in_step["in_step"]:
             v, a0 = in_step["in_step"][s.name], in_step["alone"].get(s.name)

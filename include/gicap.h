@@ -378,6 +378,18 @@ int gic_conv2d(const void* in, const void* w, void* out, float* stats, int stats
 int gic_conv2d_bn_in(const void* in, const float* in_stats, int in_nrep, const float* in_gamma, const float* in_beta, float in_count,
                      const void* w, void* out, float* stats, int stats_nrep, int dtype, int N, int H, int W, int Cin, int Cout, int KH,
                      int KW, int stride, int pad, void* stream);
+/* The 1x1 convolution that opens a bottleneck block, with the PREVIOUS block's output formed on load: its A operand is
+ *   x = relu( bn(in) + r ),   r = res (identity shortcut, res_stats == NULL) or bn_res(res) (projection shortcut),
+ * with both BatchNorms on batch statistics (sums over `count` rows: in_stats [in_nrep][2*Cin], res_stats [res_nrep][2*Cin]) --
+ * torchvision's `out = relu(bn3(conv3(..)) + identity)` followed by the next block's conv1 (src/generator.py:12-14) without the
+ * separate normalise + add + relu pass: the workgroups of the first output-channel tile also write x to block_out [N,H,W,Cin]
+ * (the next shortcut / the projection convolution read it from there).  in, res: act [N,H,W,Cin]; w act [Cout,Cin]; out act
+ * [N,H,W,Cout]; stats as gic_conv2d.  GIC_STATUS_UNSUPPORTED (nothing launched) in f32 mode, for Cin % 8 != 0 or Cin > 2048, or for
+ * shapes the 8-wave kernel does not take: the caller then runs gic_bn_act + gic_conv2d. */
+int gic_conv1x1_res_in(const void* in, const float* in_stats, int in_nrep, const float* in_gamma, const float* in_beta, const void* res,
+                       const float* res_stats, int res_nrep, const float* res_gamma, const float* res_beta, float count, void* block_out,
+                       const void* w, void* out, float* stats, int stats_nrep, int dtype, int N, int H, int W, int Cin, int Cout,
+                       void* stream);
 /* out = [relu]( bn(y) + (res ? bn_res(res) : 0) ) over rows x C.  A BatchNorm takes its mean/var from `stats` (raw sums over
  * `count` rows; train mode) or from run_mean/run_var (eval mode); res_gamma == NULL -> the residual is added as is. */
 int gic_bn_act(const void* y, const float* stats, const float* gamma, const float* beta, const float* run_mean,

@@ -104,7 +104,7 @@ def test_trunk_forward_bf16_at_bench_resolution(dev, monkeypatch):
     assert err < 5e-2
     assert rel_l2(f2, f1) < 2e-2 and rel_l2(f3, f1) < 2e-2        # BatchNorm sums are f32 atomics: not bit-reproducible
     plan = trunk._plan
-    assert sum(1 for s in plan.steps if s.fused_in) == 16 and len(plan._graphs) == 1
+    assert sum(1 for blk in plan.blocks if blk["c3"].fused_in) == 16 and len(plan._graphs) == 1
     sd = trunk.state_dict()
     assert int(sd["1.num_batches_tracked"]) == 3
     # three identical batches with momentum 0.1 from (mean 0, var 1): running = (1 - 0.9^3) * batch statistic (+ 0.9^3 for the variance)
@@ -300,6 +300,37 @@ def test_trunk_prefetch_is_equivalent(dev, dtype):
     assert outs["plain"][3] == 3 and outs["prefetch"][3] == 4
     if dtype == "fp32":
         torch.testing.assert_close(outs["plain"][2], outs["prefetch"][2], rtol=1e-3, atol=1e-5)
+
+
+def test_block_output_formed_on_load_equals_the_separate_pass(dev):
+    """gic_conv1x1_res_in (the next block's conv1 forms relu(bn3(y3) + shortcut) on load and writes the block output from its first
+    N tile) against the separate gic_bn_act pass + plain convolution: ResNet-50 trunk, bf16, every block output, the pooled feature
+    and the running statistics agree to bf16 rounding; 15 of the 16 block outputs ride in a convolution."""
+    from gan_image_captioning_amd.trunk import ResNetTrunk
+    g = torch.Generator().manual_seed(21)
+    tp = OE.make_trunk_params("resnet50", g)
+    images = torch.randn(8, 3, 96, 96, generator=g).to(dev)
+    outs = {}
+    for fused in (True, False):
+        trunk = ResNetTrunk("resnet50")
+        trunk.load_state_dict({k[len("encoder.resnet."):]: v for k, v in tp.items()}, strict=False)
+        trunk = trunk.to(dev).train()
+        trunk(images, 1)                                   # builds the plan
+        plan = trunk._plan
+        plan.fuse_res = fused
+        plan.use_graph = False
+        for s in plan.steps:
+            s.fused_in = None                              # re-probe
+        feat = trunk(images, 1).float().clone()
+        torch.cuda.synchronize()
+        blocks = [e["out"].float().clone() for e in plan._bufs[(8, 96)]["blocks"]]
+        nfused = sum(1 for blk in plan.blocks if blk["c1"].fused_in)
+        outs[fused] = (feat, blocks, nfused, trunk.state_dict()["7.2.bn3.running_var"].float().clone())
+    assert outs[True][2] == 15 and outs[False][2] == 0
+    for i, (a, b_) in enumerate(zip(outs[True][1], outs[False][1])):
+        assert rel_l2(a, b_) < 1.5e-2, f"block {i} output: rel L2 {rel_l2(a, b_):.3e}"
+    assert rel_l2(outs[True][0], outs[False][0]) < 1.5e-2
+    assert rel_l2(outs[True][3], outs[False][3]) < 2e-2
 
 
 def test_cold_and_mispredicted_trunk_passes_do_not_race_the_lookahead(dev):
