@@ -49,6 +49,7 @@ def parse():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--step-impl", default="fused", choices=["fused", "autograd"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-roofline", action="store_true", help="skip the roofline probe (profiling runs: only the timed steps' kernels)")
     p.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-oracle steps per leg (after one warm-up)")
     p.add_argument("--no-prefetch", action="store_true", help="do not hand the next batch's images to the step (no trunk prefetch)")
     p.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
@@ -297,7 +298,8 @@ def main():
                    "parallelism": "dp%d" % world},
     }
     log(f"timed region done: {elapsed / a.steps * 1e3:.3f} ms/step; roofline probe")
-    out["roofline"] = roofline_probe(inst, args, cgan, step if a.workload != "cfg4" else None)
+    if not a.no_roofline:
+        out["roofline"] = roofline_probe(inst, args, cgan, step if a.workload != "cfg4" else None)
     if world == 1 and not a.no_cpu_baseline and a.workload == "cfg2":
         out["cpu_baseline"] = cpu_baseline(a, cgan)
     print(json.dumps(out), flush=True)

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
 //     zero without touching memory -- no 64-bit address math, no branches, no zero page;
 //   * every iteration issues exactly NL DMAs, so the counted s_waitcnt is a constant and the loop body is branch-free.
 // Waves are 4 (M) x 2 (N): a wave owns 32 x BN/2 of the tile.  LDS image, swizzle and C/D layout as in the kernel above.
-template <typename TO, int BN, int EPI, bool CONV, int NS, bool ABN = false, bool ARES = false>
+template <typename TO, int BN, int EPI, bool CONV, int NS, bool ABN = false, bool ARES = false, int AMAXK = (ARES ? 2048 : 1024)>
 __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsigned a_bytes, const unsigned b_bytes) {
   static_assert(!ARES || ABN, "the residual-on-load form extends the A-side BatchNorm");
   constexpr int BM = 128, BK = 64, NT = 512;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
   constexpr int OSZ = sizeof(TO), OVE = 16 / OSZ, SC = BN * OSZ + 16;
   constexpr int EPI_BYTES = EPI == EPI_HIGHWAY ? BM * (BN + 4) * 4 : BM * SC + 8 * (BN / 2) * 2 * 4;   // highway stages h in f32
   constexpr int RING_BYTES = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
-  constexpr int ABN_MAXK = ARES ? 2048 : 1024;                // A-side BatchNorm: [scale, shift] per input channel behind the ring
+  constexpr int ABN_MAXK = AMAXK;                             // A-side BatchNorm: [scale, shift] per input channel behind the ring
   constexpr int SMEM_BYTES = RING_BYTES + (ABN ? ABN_MAXK * 8 : 0) + (ARES ? ABN_MAXK * 8 : 0);     // ARES: + the shortcut's [scale, shift]
   constexpr unsigned OOB = 0x80000000u;                       // >= any extent this kernel is launched with
   static_assert(CB >= 1 && SMEM_BYTES <= 160 * 1024, "tile8 LDS budget");
@@ -1023,8 +1023,26 @@ bool try_tile8(const GemmDesc& d, hipStream_t stream) {
       const bool n128 = d.N >= 128;
       const long tiles = n128 ? big_tiles : (long)cdiv(d.M, 128) * cdiv(d.N, 64);
       const dim3 grid((unsigned)tiles), block(512);
-      if (n128) hipLaunchKernelGGL((tile8_kernel<TO, 128, EPI, CONV, 2, true, true>), grid, block, 0, stream, d, ab, bb);
-      else hipLaunchKernelGGL((tile8_kernel<TO, 64, EPI, CONV, 2, true, true>), grid, block, 0, stream, d, ab, bb);
+      // ring-less (one stage: two A-side tiles + B): 2-3 workgroups share a CU and cover each other's DMA latency and LDS rewrite;
+      // the coefficient table is sized by the channel count (512 -> 8 KB, 2048 -> 32 KB)
+      static const int res_ns = [] { const char* e = getenv("GIC_TILE8_RES_NS"); return e ? atoi(e) : 1; }();
+      if (d.cCin <= 512) {
+        if (res_ns == 1) {
+          if (n128) hipLaunchKernelGGL((tile8_kernel<TO, 128, EPI, CONV, 1, true, true, 512>), grid, block, 0, stream, d, ab, bb);
+          else hipLaunchKernelGGL((tile8_kernel<TO, 64, EPI, CONV, 1, true, true, 512>), grid, block, 0, stream, d, ab, bb);
+        } else {
+          if (n128) hipLaunchKernelGGL((tile8_kernel<TO, 128, EPI, CONV, 2, true, true, 512>), grid, block, 0, stream, d, ab, bb);
+          else hipLaunchKernelGGL((tile8_kernel<TO, 64, EPI, CONV, 2, true, true, 512>), grid, block, 0, stream, d, ab, bb);
+        }
+      } else {
+        if (res_ns == 1) {
+          if (n128) hipLaunchKernelGGL((tile8_kernel<TO, 128, EPI, CONV, 1, true, true, 2048>), grid, block, 0, stream, d, ab, bb);
+          else hipLaunchKernelGGL((tile8_kernel<TO, 64, EPI, CONV, 1, true, true, 2048>), grid, block, 0, stream, d, ab, bb);
+        } else {
+          if (n128) hipLaunchKernelGGL((tile8_kernel<TO, 128, EPI, CONV, 2, true, true, 2048>), grid, block, 0, stream, d, ab, bb);
+          else hipLaunchKernelGGL((tile8_kernel<TO, 64, EPI, CONV, 2, true, true, 2048>), grid, block, 0, stream, d, ab, bb);
+        }
+      }
       return true;
     }
     if (d.in_stats) {      // A-side BatchNorm + ReLU: whole 16-byte chunks per tap, channels within the LDS table

@@ -94,6 +94,7 @@ class TrunkPlan:
         self._warm: set = set()
         self.fuse_in = not os.environ.get("GIC_NO_FUSED_BN_IN")
         self.fuse_res = not os.environ.get("GIC_NO_FUSED_RES_IN")        # block outputs formed on load by the next conv1 (gic_conv1x1_res_in)
+        self.res_min_rows = int(os.environ.get("GIC_RES_IN_MIN_ROWS", "50000"))
         self._nrep = {}
         self.use_graph = not os.environ.get("GIC_NO_GRAPH")
         self.pending_tracked = 0
@@ -237,7 +238,9 @@ class TrunkPlan:
         """conv1 of a block whose input (the previous block's output) is still pending: formed on load and written to its buffer by
         the convolution itself.  pend = (last step, its raw output, shortcut tensor, shortcut step | None, rows, out buffer)."""
         last, ylast, res, res_step, rows, out = pend
-        if c1.fused_in is False or c1.k != 1 or c1.stride != 1:
+        # measured (profiles/, cfg2): the fused launch beats bn_act + plain convolution where the grid is large (>= ~390 row tiles: the
+        # 56x56 and 28x28 inputs at batch 64: -8..-15 us per block); on small grids the ring-less fused kernel is latency-bound
+        if c1.fused_in is False or c1.k != 1 or c1.stride != 1 or rows < self.res_min_rows:
             return False
         base = stats.data_ptr()
         rs = base + 4 * res_step.stats_off if res_step is not None else None
