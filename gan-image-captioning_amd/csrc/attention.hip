@@ -57,13 +57,11 @@ constexpr int kAttnMaxP = 1024;      // positions per caption (LDS tables)
 constexpr int kAttnMaxA = 2048;      // attention width (LDS table)
 
 struct AttnFwdArgs {
-  const void* h_prev; long ld_h;     // act: h_{t-1} rows (XH_t + E + C)
-  const void* wh;                    // act [A, H]
   const void* fproj;                 // act [B, P, A]
   const float* w_a;                  // [A]
   const void* fmap;                  // act [B, P, C]
   float* alpha;                      // [B, P] out (saved)
-  float* hproj;                      // [B, A] out (saved)
+  const float* hproj;                // [B, A] = h_{t-1} W_h^T (saved)
   void* z; long ld_z;                // act: z_t rows (XH_t + E)
   int P, A, H, C;
 };
@@ -72,27 +70,12 @@ template <typename TA>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
   constexpr int NV = Vec16<TA>::NV;
   extern __shared__ float af_smem[];
-  float* h_s = af_smem;                    // [H]
-  float* hp_s = h_s + a.H;                 // [A]
+  float* hp_s = af_smem;                   // [A]
   float* e_s = hp_s + a.A;                 // [P]
   __shared__ float red[16];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const TA* hrow = (const TA*)a.h_prev + (long)b * a.ld_h;
-  for (int k = tid; k < a.H; k += 256) h_s[k] = to_f32<TA>(hrow[k]);
-  __syncthreads();
-  // hp[j] = W_h[j, :] . h  -- one wave per row, lanes over k (coalesced 16-byte pieces of the row)
-  const TA* wh = (const TA*)a.wh;
-  for (int j = w; j < a.A; j += 4) {
-    float s = 0.f;
-    for (int k0 = lane * NV; k0 < a.H; k0 += 64 * NV) {
-      float v[NV];
-      Vec16<TA>::load(wh + (long)j * a.H + k0, v);
-#pragma unroll
-      for (int i = 0; i < NV; ++i) s += v[i] * h_s[k0 + i];
-    }
-    s = wave_sum(s);
-    if (lane == 0) { hp_s[j] = s; a.hproj[(long)b * a.A + j] = s; }
-  }
+  // hp = W_h h_{t-1} was formed for all captions by one MFMA product (the launcher below): this block's row
+  for (int j = tid; j < a.A; j += 256) hp_s[j] = a.hproj[(long)b * a.A + j];
   __syncthreads();
   // e_i = w_a . tanh(fp_i + hp)  -- one wave per position
   const TA* fp = (const TA*)a.fproj + (long)b * a.P * a.A;
@@ -148,11 +131,9 @@ struct AttnBwdArgs {
   const void* fproj;                 // act [B, P, A]
   const void* fmap;                  // act [B, P, C]
   const float* w_a;                  // [A]
-  const void* wh;                    // act [A, H]
   float* dfproj;                     // [B, P, A] accumulated over the steps (zeroed by the caller)
-  void* dhproj;                      // act [B, A] of this step (operand of the W_h weight gradient)
+  void* dhproj;                      // act [B, A] of this step (operand of the W_h weight gradient and of dh_{t-1} += dhp W_h)
   float* dwa_rows;                   // [B, A] accumulated over the steps (zeroed by the caller): d w_a per caption
-  float* dh_extra;                   // [B, H] out: W_h^T dhp
   int P, A, H, C;
 };
 
@@ -225,24 +206,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
     dhp_s[j] = s;
     ((TA*)a.dhproj)[(long)b * a.A + j] = from_f32<TA>(s);
   }
-  __syncthreads();
-  // dh_{t-1} += W_h^T d hp : threads over 16-byte pieces of the hidden row (coalesced along k), rows of W_h streamed
-  const TA* wh = (const TA*)a.wh;
-  for (int k0 = tid * NV; k0 < a.H; k0 += 256 * NV) {
-    float acc[NV];
-#pragma unroll
-    for (int q = 0; q < NV; ++q) acc[q] = 0.f;
-#pragma unroll 4
-    for (int j = 0; j < a.A; ++j) {
-      float v[NV];
-      Vec16<TA>::load(wh + (long)j * a.H + k0, v);
-      const float d = dhp_s[j];
-#pragma unroll
-      for (int q = 0; q < NV; ++q) acc[q] += d * v[q];
-    }
-#pragma unroll
-    for (int q = 0; q < NV; ++q) a.dh_extra[(long)b * a.H + k0 + q] = acc[q];
-  }
 }
 
 struct ACtx {
@@ -297,13 +260,19 @@ int attn_fwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S
   float* part_s = st->part + per;
   unsigned long long* rowkey = (unsigned long long*)(st->part + ((2 * per + 1) & ~1l));
   GIC_PROPAGATE(fill_zero(rowkey, (size_t)L * B * sizeof(unsigned long long), stream));
-  const size_t lds = (size_t)(H + c.A + c.P) * sizeof(float);
+  const size_t lds = (size_t)(c.A + c.P) * sizeof(float);
   static size_t granted = 64 * 1024;
   GIC_PROPAGATE(grant_lds(attn_fwd_kernel<TA>, lds, granted));
   for (int t = 0; t < L; ++t) {
     TA* xh_t = (TA*)st->xh + (long)t * B * ld;
+    {  // hp [B, A] = h_{t-1} W_h^T for all captions: one product
+      GemmDesc g;
+      g.A = xh_t + c.din(); g.lda = ld; g.B = S->wh; g.ldb = H; g.C = st->hproj + (long)t * B * c.A; g.ldc = c.A;
+      g.M = B; g.N = c.A; g.K = H; g.in_dtype = c.dt; g.out_dtype = DT_F32;
+      GIC_PROPAGATE(gemm(g, stream));
+    }
     AttnFwdArgs f;
-    f.h_prev = xh_t + c.din(); f.ld_h = ld; f.wh = S->wh; f.fproj = st->fproj; f.w_a = P->w_a; f.fmap = fmap;
+    f.fproj = st->fproj; f.w_a = P->w_a; f.fmap = fmap;
     f.alpha = st->alpha + (long)t * B * c.P; f.hproj = st->hproj + (long)t * B * c.A; f.z = xh_t + E; f.ld_z = ld;
     f.P = c.P; f.A = c.A; f.H = H; f.C = c.C;
     hipLaunchKernelGGL((attn_fwd_kernel<TA>), dim3(B), dim3(256), lds, stream, f);
@@ -362,10 +331,16 @@ int attn_bwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S
     }
     AttnBwdArgs f;
     f.dz = ws->dz; f.alpha = st->alpha + (long)t * B * c.P; f.hproj = st->hproj + (long)t * B * A; f.fproj = st->fproj; f.fmap = fmap;
-    f.w_a = P->w_a; f.wh = S->wh; f.dfproj = ws->dfproj; f.dhproj = (TA*)ws->dhproj + (long)t * B * A; f.dwa_rows = ws->dwa_rows;
-    f.dh_extra = ws->dh_extra; f.P = c.P; f.A = A; f.H = H; f.C = C;
+    f.w_a = P->w_a; f.dfproj = ws->dfproj; f.dhproj = (TA*)ws->dhproj + (long)t * B * A; f.dwa_rows = ws->dwa_rows;
+    f.P = c.P; f.A = A; f.H = H; f.C = C;
     hipLaunchKernelGGL((attn_bwd_kernel<TA>), dim3(B), dim3(256), lds, stream, f);
     GIC_CHECK_LAUNCH("attn_bwd");
+    if (t > 0) {  // dh_{t-1} += dhp_t W_h  (consumed by the next lstm_bwd_step as dh_extra)
+      GemmDesc g;
+      g.A = f.dhproj; g.lda = A; g.a_kc = 1; g.B = S->wh; g.ldb = H; g.b_kc = 0; g.C = ws->dh_extra; g.ldc = H;
+      g.M = B; g.N = H; g.K = A; g.in_dtype = c.dt; g.out_dtype = DT_F32;
+      GIC_PROPAGATE(gemm(g, stream));
+    }
   }
   // ---- batched over all steps
   {  // d x_t [L*B, E] = dgates W_x  (rows 0..E-1 of Wcat^T)

@@ -188,30 +188,42 @@ __global__ __launch_bounds__(1024) void gumbel_softmax_argmax_reg_kernel(
       for (int k = 0; k < 4; ++k) y[e][k] = -INFINITY;
     }
   }
-  mx = block_max(mx, red);
-  float sm = 0.f;
-  float ex[QPT][4];
-#pragma unroll
-  for (int e = 0; e < QPT; ++e)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      ex[e][k] = FAST ? __expf(y[e][k] - mx) : expf(y[e][k] - mx);       // exp(-inf) = 0 for the padding
-      sm += ex[e][k];
-    }
-  sm = block_sum(sm, red);
-  float best = -1.f;
+  float best = -INFINITY;
   int best_i = 0x7fffffff;
+  if (!orow) {
+    // ids only (inference roll-outs): the softmax is monotone, so the first maximal index of y is the token -- no exp, no sum
 #pragma unroll
-  for (int e = 0; e < QPT; ++e) {
-    const int q = tid + e * 1024;
-    if (q < nq) {
-      float p[4];
+    for (int e = 0; e < QPT; ++e) {
+      const int q = tid + e * 1024;
+      if (q < nq) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (y[e][k] > best) { best = y[e][k]; best_i = 4 * q + k; }
+      }
+    }
+  } else {
+    mx = block_max(mx, red);
+    float sm = 0.f;
+    float ex[QPT][4];
+#pragma unroll
+    for (int e = 0; e < QPT; ++e)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        p[k] = ex[e][k] / sm;
-        if (p[k] > best) { best = p[k]; best_i = 4 * q + k; }
+        ex[e][k] = FAST ? __expf(y[e][k] - mx) : expf(y[e][k] - mx);       // exp(-inf) = 0 for the padding
+        sm += ex[e][k];
       }
-      if (orow) {
+    sm = block_sum(sm, red);
+    best = -1.f;
+#pragma unroll
+    for (int e = 0; e < QPT; ++e) {
+      const int q = tid + e * 1024;
+      if (q < nq) {
+        float p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          p[k] = ex[e][k] / sm;
+          if (p[k] > best) { best = p[k]; best_i = 4 * q + k; }
+        }
         TA o4[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) o4[k] = from_f32<TA>(pretrain ? y[e][k] : p[k]);
