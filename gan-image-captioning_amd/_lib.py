@@ -76,7 +76,7 @@ class AttnState(C.Structure):
 
 
 class AttnBwdWs(C.Structure):
-    _fields_ = [(n, c_void_p) for n in ("dlogits", "dhout", "dgates", "dc", "dz", "dh_extra", "dhproj", "dfproj", "dfproj_act", "dwa_rows", "dx")]
+    _fields_ = [(n, c_void_p) for n in ("dlogits", "dhout", "dgates", "dc", "dz", "dalpha", "dh_extra", "dhproj", "dfproj", "dfproj_act", "dwa_rows", "dx")]
 
 
 class DiscDims(C.Structure):

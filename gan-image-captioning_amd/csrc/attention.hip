@@ -131,80 +131,86 @@ struct AttnBwdArgs {
   const void* fproj;                 // act [B, P, A]
   const void* fmap;                  // act [B, P, C]
   const float* w_a;                  // [A]
+  float* dalpha;                     // [B, P] scratch: dz . fmap_i
   float* dfproj;                     // [B, P, A] accumulated over the steps (zeroed by the caller)
   void* dhproj;                      // act [B, A] of this step (operand of the W_h weight gradient and of dh_{t-1} += dhp W_h)
   float* dwa_rows;                   // [B, A] accumulated over the steps (zeroed by the caller): d w_a per caption
   int P, A, H, C;
 };
 
+// d alpha[b, i] = dz[b, :] . fmap[b, i, :]  -- one wave per (caption, position): B*P/4 blocks, coalesced 16-byte feature loads
+template <typename TA>
+__global__ __launch_bounds__(256) void attn_dalpha_kernel(const AttnBwdArgs a, int B) {
+  constexpr int NV = Vec16<TA>::NV;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // b * P + i
+  if (row >= (long)B * a.P) return;
+  const int b = (int)(row / a.P);
+  const TA* f = (const TA*)a.fmap + row * a.C;
+  const float* dz = a.dz + (long)b * a.C;
+  float s = 0.f;
+  for (int c0 = lane * NV; c0 < a.C; c0 += 64 * NV) {
+    float v[NV];
+    Vec16<TA>::load(f + c0, v);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) s += v[q] * dz[c0 + q];
+  }
+  s = wave_sum(s);
+  if (lane == 0) a.dalpha[row] = s;
+}
+
+// softmax backward + tanh backward for a slice of 64*NV attention columns of one caption (grid = A/(64 NV) x B): de is recomputed per
+// block from d alpha (P values); each of the 4 waves sweeps every 4th position over the block's columns, one 16-byte piece per lane;
+// d hp of the slice (sum over ALL positions) is complete inside the block, d fp rows are this caption's own (no atomics).
 template <typename TA>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
   constexpr int NV = Vec16<TA>::NV;
   extern __shared__ float ab_smem[];
-  float* dz_s = ab_smem;                   // [C]
-  float* hp_s = dz_s + a.C;                // [A]
-  float* de_s = hp_s + a.A;                // [P]
-  float* dhp_s = de_s + a.P;               // [4][A] per-wave partial sums, then the total in row 0
+  float* de_s = ab_smem;                   // [P]
+  float* dhp_s = de_s + a.P;               // [4][64*NV]
+  float* dwa_s = dhp_s + 4 * 64 * NV;      // [4][64*NV]
   __shared__ float red[16];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int c = tid; c < a.C; c += 256) dz_s[c] = a.dz[(long)b * a.C + c];
-  for (int j = tid; j < a.A; j += 256) hp_s[j] = a.hproj[(long)b * a.A + j];
-  for (int j = tid; j < 4 * a.A; j += 256) dhp_s[j] = 0.f;
-  __syncthreads();
-  // d alpha_i = dz . fmap_i  -- one wave per position
-  const TA* fm = (const TA*)a.fmap + (long)b * a.P * a.C;
-  for (int i = w; i < a.P; i += 4) {
-    float s = 0.f;
-    for (int c0 = lane * NV; c0 < a.C; c0 += 64 * NV) {
-      float v[NV];
-      Vec16<TA>::load(fm + (long)i * a.C + c0, v);
-#pragma unroll
-      for (int q = 0; q < NV; ++q) s += v[q] * dz_s[c0 + q];
-    }
-    s = wave_sum(s);
-    if (lane == 0) de_s[i] = s;
-  }
-  __syncthreads();
-  // softmax backward: de_i = alpha_i (dalpha_i - sum_j alpha_j dalpha_j)
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j0 = blockIdx.x * 64 * NV + lane * NV;                     // this lane's columns
   float dot = 0.f;
-  for (int i = tid; i < a.P; i += 256) dot += a.alpha[(long)b * a.P + i] * de_s[i];
+  for (int i = tid; i < a.P; i += 256) dot += a.alpha[(long)b * a.P + i] * a.dalpha[(long)b * a.P + i];
   dot = block_sum(dot, red);
+  for (int i = tid; i < a.P; i += 256) de_s[i] = a.alpha[(long)b * a.P + i] * (a.dalpha[(long)b * a.P + i] - dot);
   __syncthreads();
-  for (int i = tid; i < a.P; i += 256) de_s[i] = a.alpha[(long)b * a.P + i] * (de_s[i] - dot);
-  __syncthreads();
-  // tanh backward: per position (one wave each) d pre = de_i w_a (1 - th^2); accumulates d fp (this caption's own rows: no
-  // atomics), d hp (sum over positions) and d w_a (th de_i, sum over positions) per lane-owned column, then across the 4 waves
-  const TA* fp = (const TA*)a.fproj + (long)b * a.P * a.A;
-  float* dfp = a.dfproj + (long)b * a.P * a.A;
-  for (int j0 = lane * NV; j0 < a.A; j0 += 64 * NV) {
-    float dhp[NV], dwa[NV];
+  float dhp[NV], dwa[NV];
 #pragma unroll
-    for (int q = 0; q < NV; ++q) { dhp[q] = 0.f; dwa[q] = 0.f; }
+  for (int q = 0; q < NV; ++q) { dhp[q] = 0.f; dwa[q] = 0.f; }
+  if (j0 < a.A) {
+    const TA* fp = (const TA*)a.fproj + (long)b * a.P * a.A;
+    float* dfp = a.dfproj + (long)b * a.P * a.A;
+    float hp[NV], wa[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) { hp[q] = a.hproj[(long)b * a.A + j0 + q]; wa[q] = a.w_a[j0 + q]; }
     for (int i = w; i < a.P; i += 4) {
       float v[NV];
       Vec16<TA>::load(fp + (long)i * a.A + j0, v);
       const float de = de_s[i];
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
-        const float th = tanhf(v[q] + hp_s[j0 + q]);
-        const float dpre = de * a.w_a[j0 + q] * (1.f - th * th);
+        const float th = tanhf(v[q] + hp[q]);
+        const float dpre = de * wa[q] * (1.f - th * th);
         dfp[(long)i * a.A + j0 + q] += dpre;
         dhp[q] += dpre;
         dwa[q] += de * th;
       }
     }
-    // d hp partials of the 4 waves meet in LDS; d w_a partials are added into the caption's own row (4 adders per address)
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      dhp_s[w * a.A + j0 + q] = dhp[q];
-      atomicAdd(&a.dwa_rows[(long)b * a.A + j0 + q], dwa[q]);
-    }
   }
+#pragma unroll
+  for (int q = 0; q < NV; ++q) { dhp_s[(w * 64 + lane) * NV + q] = dhp[q]; dwa_s[(w * 64 + lane) * NV + q] = dwa[q]; }
   __syncthreads();
-  for (int j = tid; j < a.A; j += 256) {
-    const float s = dhp_s[j] + dhp_s[a.A + j] + dhp_s[2 * a.A + j] + dhp_s[3 * a.A + j];
-    dhp_s[j] = s;
-    ((TA*)a.dhproj)[(long)b * a.A + j] = from_f32<TA>(s);
+  for (int c = tid; c < 64 * NV; c += 256) {
+    const int j = blockIdx.x * 64 * NV + c;
+    if (j < a.A) {
+      const float sh = dhp_s[c] + dhp_s[64 * NV + c] + dhp_s[2 * 64 * NV + c] + dhp_s[3 * 64 * NV + c];
+      const float sw = dwa_s[c] + dwa_s[64 * NV + c] + dwa_s[2 * 64 * NV + c] + dwa_s[3 * 64 * NV + c];
+      ((TA*)a.dhproj)[(long)b * a.A + j] = from_f32<TA>(sh);
+      a.dwa_rows[(long)b * a.A + j] += sw;                             // this block owns (b, j): plain accumulate over the steps
+    }
   }
 }
 
@@ -311,9 +317,8 @@ int attn_bwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S
   GIC_PROPAGATE(fill_zero(ws->dc, (size_t)B * H * sizeof(float), stream));
   GIC_PROPAGATE(fill_zero(ws->dfproj, (size_t)B * c.P * A * sizeof(float), stream));
   GIC_PROPAGATE(fill_zero(ws->dwa_rows, (size_t)B * A * sizeof(float), stream));
-  const size_t lds = (size_t)(C + A + c.P + 4 * A) * sizeof(float);
-  static size_t granted = 64 * 1024;
-  GIC_PROPAGATE(grant_lds(attn_bwd_kernel<TA>, lds, granted));
+  constexpr int kCols = 64 * Vec16<TA>::NV;                       // attention columns per attn_bwd block
+  const size_t lds = (size_t)(c.P + 8 * kCols) * sizeof(float);
   const TA* wt = (const TA*)S->wcat_t;                      // [ldx, 4H]: rows 0..E-1 x, E..E+C-1 z, E+C.. h
   for (int t = L - 1; t >= 0; --t) {
     LstmBwdStepArgs a;
@@ -331,9 +336,11 @@ int attn_bwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S
     }
     AttnBwdArgs f;
     f.dz = ws->dz; f.alpha = st->alpha + (long)t * B * c.P; f.hproj = st->hproj + (long)t * B * A; f.fproj = st->fproj; f.fmap = fmap;
-    f.w_a = P->w_a; f.dfproj = ws->dfproj; f.dhproj = (TA*)ws->dhproj + (long)t * B * A; f.dwa_rows = ws->dwa_rows;
+    f.w_a = P->w_a; f.dalpha = ws->dalpha; f.dfproj = ws->dfproj; f.dhproj = (TA*)ws->dhproj + (long)t * B * A; f.dwa_rows = ws->dwa_rows;
     f.P = c.P; f.A = A; f.H = H; f.C = C;
-    hipLaunchKernelGGL((attn_bwd_kernel<TA>), dim3(B), dim3(256), lds, stream, f);
+    hipLaunchKernelGGL((attn_dalpha_kernel<TA>), dim3((unsigned)cdiv((long)B * c.P, 4)), dim3(256), 0, stream, f, B);
+    GIC_CHECK_LAUNCH("attn_dalpha");
+    hipLaunchKernelGGL((attn_bwd_kernel<TA>), dim3((unsigned)cdiv(A, kCols), (unsigned)B), dim3(256), lds, stream, f);
     GIC_CHECK_LAUNCH("attn_bwd");
     if (t > 0) {  // dh_{t-1} += dhp_t W_h  (consumed by the next lstm_bwd_step as dh_extra)
       GemmDesc g;
@@ -426,7 +433,7 @@ int gic_attn_sample_bwd(const gic_attn_dims* dims, const gic_attn_params* P, con
   GIC_PROPAGATE(check_attn_dims(dims, c));
   GIC_CHECK_ARG(P && S && st && ws && fmap && probs && ids && d_out && G, "attn_sample_bwd: null argument");
   GIC_CHECK_ARG(S->wcat_t && S->wout && S->wh && P->w_a, "attn_sample_bwd: null weights");
-  GIC_CHECK_ARG(ws->dlogits && ws->dhout && ws->dgates && ws->dc && ws->dz && ws->dh_extra && ws->dhproj && ws->dfproj && ws->dwa_rows && ws->dx &&
+  GIC_CHECK_ARG(ws->dlogits && ws->dhout && ws->dgates && ws->dc && ws->dz && ws->dalpha && ws->dh_extra && ws->dhproj && ws->dfproj && ws->dwa_rows && ws->dx &&
                 (c.dt == DT_F32 || ws->dfproj_act), "attn_sample_bwd: null workspace buffer");
   GIC_CHECK_ARG(G->embed && G->w_ih && G->w_hh && G->b_ih && G->b_hh && G->w_out && G->b_out && G->w_f && G->b_f && G->w_h && G->w_a && G->features,
                 "attn_sample_bwd: null gradient buffer");

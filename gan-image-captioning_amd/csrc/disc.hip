@@ -82,83 +82,54 @@ __device__ __forceinline__ void conv_max_s1(const float* __restrict__ xs, const 
   }
 }
 
-// ---- fused conv + bias + ReLU + max-over-time.  A block owns RPB consecutive (caption, representation) rows; its 256 threads stride
-// over the F filters.  A thread loads its filter's taps and bias ONCE (registers) and sweeps the block's rows with them: one row per
-// block re-read every filter from L2 for 20 input values (measured 35 us at 4096 rows, 1.35 ms at the 622 k rows of a Monte-Carlo batch).
-constexpr int kConvRowsPerBlock = 16;
+// ---- fused conv + bias + ReLU + max-over-time.  grid = B*R blocks, 256 threads stride over the F filters.
 template <typename TA, int MAXT>
-__global__ __launch_bounds__(256) void disc_conv_pool_fwd_kernel(const float* __restrict__ emb, ConvMeta cm, int L, int De, int R, long rowsBR,
+__global__ __launch_bounds__(256) void disc_conv_pool_fwd_kernel(const float* __restrict__ emb, ConvMeta cm, int L, int De, int R,
                                                                    TA* __restrict__ pooled, uint8_t* __restrict__ argmax) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];   // [RPB][L*s]
-  constexpr int RPB = kConvRowsPerBlock;
-  const int s = cm.s, ls = L * s;
-  const long br0 = (long)blockIdx.x * RPB;
-  for (int i = threadIdx.x; i < RPB * ls; i += 256) {
-    const int rr = i / ls, ii = i - rr * ls;
-    const long br = br0 + rr;
-    float v = 0.f;
-    if (br < rowsBR) {
-      const long b = br / R;
-      const int r = (int)(br % R);
-      v = emb[(b * L + ii / s) * De + r * s + ii % s];
-    }
-    xs[i] = v;
-  }
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // [L][s]
+  const int br = blockIdx.x, b = br / R, r = br % R, s = cm.s;
+  for (int i = threadIdx.x; i < L * s; i += 256) xs[i] = emb[((long)b * L + i / s) * De + r * s + i % s];
   __syncthreads();
   for (int col = threadIdx.x; col < cm.Fp; col += 256) {
-    int f = 0, taps = 0;
-    float bias = 0.f;
-    float w[MAXT];
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) w[j] = 0.f;
+    float best = 0.f;
+    int bt = 0;
     if (col < cm.F) {
       const int k = conv_of(cm, col);
-      const int ch = col - cm.foff[k];
-      f = cm.fsize[k];
-      taps = f * s;
-      bias = cm.b[k][ch];
+      const int f = cm.fsize[k], ch = col - cm.foff[k], taps = f * s;
+      const float bias = cm.b[k][ch];
       const float* wp = cm.w[k] + (long)ch * taps;
-#pragma unroll
-      for (int j = 0; j < MAXT; ++j)
-        if (j < taps) w[j] = wp[j];
-    }
-    for (int rr = 0; rr < RPB; ++rr) {
-      const long br = br0 + rr;
-      if (br >= rowsBR) break;
-      const float* x = xs + rr * ls;
-      float best = 0.f;
-      int bt = 0;
-      if (col < cm.F) {
-        bool done = false;
-        if (s == 1) {
-          done = true;
-          switch (f) {
-            case 1: conv_max_s1<1>(x, w, bias, L, best, bt); break;
-            case 2: conv_max_s1<2>(x, w, bias, L, best, bt); break;
-            case 3: conv_max_s1<3>(x, w, bias, L, best, bt); break;
-            case 4: conv_max_s1<4>(x, w, bias, L, best, bt); break;
-            case 5: conv_max_s1<5>(x, w, bias, L, best, bt); break;
-            case 6: conv_max_s1<6>(x, w, bias, L, best, bt); break;
-            case 7: conv_max_s1<7>(x, w, bias, L, best, bt); break;
-            case 8: conv_max_s1<8>(x, w, bias, L, best, bt); break;
-            default: done = false;
-          }
-        }
-        if (!done) {
-          best = -1.f;
-          for (int t = 0; t + f <= L; ++t) {
-            float v = bias;
-#pragma unroll
-            for (int j = 0; j < MAXT; ++j)
-              if (j < taps) v += w[j] * x[t * s + j];       // window (t..t+f-1) x s is contiguous in xs
-            v = fmaxf(v, 0.f);                              // relu then max (discriminator.py:42,45)
-            if (v > best) { best = v; bt = t; }
-          }
+      bool done = false;
+      if (s == 1) {
+        done = true;
+        switch (f) {
+          case 1: conv_max_s1<1>(xs, wp, bias, L, best, bt); break;
+          case 2: conv_max_s1<2>(xs, wp, bias, L, best, bt); break;
+          case 3: conv_max_s1<3>(xs, wp, bias, L, best, bt); break;
+          case 4: conv_max_s1<4>(xs, wp, bias, L, best, bt); break;
+          case 5: conv_max_s1<5>(xs, wp, bias, L, best, bt); break;
+          case 6: conv_max_s1<6>(xs, wp, bias, L, best, bt); break;
+          case 7: conv_max_s1<7>(xs, wp, bias, L, best, bt); break;
+          case 8: conv_max_s1<8>(xs, wp, bias, L, best, bt); break;
+          default: done = false;
         }
       }
-      pooled[br * cm.Fp + col] = from_f32<TA>(best);
-      argmax[br * cm.Fp + col] = (uint8_t)bt;
+      if (!done) {
+        float w[MAXT];
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) w[j] = j < taps ? wp[j] : 0.f;
+        best = -1.f;
+        for (int t = 0; t + f <= L; ++t) {
+          float v = bias;
+#pragma unroll
+          for (int j = 0; j < MAXT; ++j)
+            if (j < taps) v += w[j] * xs[t * s + j];      // window (t..t+f-1) x s is contiguous in xs
+          v = fmaxf(v, 0.f);                              // relu then max (discriminator.py:42,45)
+          if (v > best) { best = v; bt = t; }
+        }
+      }
     }
+    pooled[(long)br * cm.Fp + col] = from_f32<TA>(best);
+    argmax[(long)br * cm.Fp + col] = (uint8_t)bt;
   }
 }
 
@@ -433,13 +404,11 @@ int disc_fwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
   int max_taps = 0;
   for (int k = 0; k < c.cm.nconv; ++k) max_taps = c.cm.fsize[k] * c.s > max_taps ? c.cm.fsize[k] * c.s : max_taps;
   if (max_taps <= 8)
-    hipLaunchKernelGGL((disc_conv_pool_fwd_kernel<TA, 8>), dim3((unsigned)cdiv(c.rowsBR, kConvRowsPerBlock)), dim3(256),
-                       (size_t)kConvRowsPerBlock * c.L * c.s * sizeof(float), stream, (const float*)st->emb, c.cm, c.L, c.De, c.R, c.rowsBR,
-                       (TA*)st->pooled, st->argmax);
+    hipLaunchKernelGGL((disc_conv_pool_fwd_kernel<TA, 8>), dim3((unsigned)c.rowsBR), dim3(256), c.L * c.s * sizeof(float), stream,
+                       (const float*)st->emb, c.cm, c.L, c.De, c.R, (TA*)st->pooled, st->argmax);
   else
-    hipLaunchKernelGGL((disc_conv_pool_fwd_kernel<TA, kMaxTaps>), dim3((unsigned)cdiv(c.rowsBR, kConvRowsPerBlock)), dim3(256),
-                       (size_t)kConvRowsPerBlock * c.L * c.s * sizeof(float), stream, (const float*)st->emb, c.cm, c.L, c.De, c.R, c.rowsBR,
-                       (TA*)st->pooled, st->argmax);
+    hipLaunchKernelGGL((disc_conv_pool_fwd_kernel<TA, kMaxTaps>), dim3((unsigned)c.rowsBR), dim3(256), c.L * c.s * sizeof(float), stream,
+                       (const float*)st->emb, c.cm, c.L, c.De, c.R, (TA*)st->pooled, st->argmax);
   GIC_CHECK_LAUNCH("disc_conv_pool_fwd");
   // 3. highway + dropout (fused epilogue)
   {

@@ -766,6 +766,7 @@ class AttnDecoderEngine:
             "dgates": torch.empty(Lc, B, 4 * self.H, device=dev, dtype=self.act),
             "dc": torch.empty(B, self.H, device=dev, dtype=f32),
             "dz": torch.empty(B, self.C, device=dev, dtype=f32),
+            "dalpha": torch.empty(B, self.P, device=dev, dtype=f32),
             "dh_extra": torch.empty(B, self.H, device=dev, dtype=f32),
             "dhproj": torch.empty(Lc, B, self.A, device=dev, dtype=self.act),
             "dfproj": torch.empty(B, self.P, self.A, device=dev, dtype=f32),

@@ -245,6 +245,7 @@ typedef struct gic_attn_bwd_ws {
   void* dgates;                          /* act [L, B, 4H] */
   float* dc;                             /* [B, H] */
   float* dz;                             /* [B, C] */
+  float* dalpha;                         /* [B, P] */
   float* dh_extra;                       /* [B, H] */
   void* dhproj;                          /* act [L, B, A] */
   float* dfproj;                         /* [B, P, A] */
