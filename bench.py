@@ -299,7 +299,9 @@ def main():
     }
     log(f"timed region done: {elapsed / a.steps * 1e3:.3f} ms/step; roofline probe")
     if not a.no_roofline:
-        out["roofline"] = roofline_probe(inst, args, cgan, step if a.workload != "cfg4" else None)
+        # the in-step measurement runs train steps: only without data parallelism (the other ranks have left; a step would wait for
+        # them in its all-reduce) -- with N > 1 the line carries the isolated replay of rank 0
+        out["roofline"] = roofline_probe(inst, args, cgan, step if (a.workload != "cfg4" and world == 1) else None)
     if world == 1 and not a.no_cpu_baseline and a.workload == "cfg2":
         out["cpu_baseline"] = cpu_baseline(a, cgan)
     print(json.dumps(out), flush=True)
