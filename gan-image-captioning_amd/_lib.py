@@ -47,7 +47,8 @@ class DecoderState(C.Structure):
 
 
 class DecoderSampleOpts(C.Structure):
-    _fields_ = [("h0", c_void_p), ("c0", c_void_p), ("force_ids", c_void_p), ("force_len", c_void_p), ("no_state", C.c_int32)]
+    _fields_ = [("h0", c_void_p), ("c0", c_void_p), ("force_ids", c_void_p), ("force_len", c_void_p), ("no_state", C.c_int32),
+                ("resume_from", c_void_p), ("resume_B", C.c_int32), ("host_active_rows", c_void_p)]
 
 
 class DecoderBwdWs(C.Structure):

@@ -286,6 +286,23 @@ __global__ void build_wcat_kernel(const float* __restrict__ w_ih, const float* _
   }
 }
 
+// Resumed roll-outs: rows [r0, r1) join at this step with the recurrent state of caption r % srcB of an earlier call (one slot of
+// its XH and c buffers): row copies of `rowbytes` (16-byte pieces) and H floats.
+__global__ void rollout_join_kernel(const unsigned char* __restrict__ src_xh, unsigned char* __restrict__ dst_xh, long rowbytes,
+                                    const float* __restrict__ src_c, float* __restrict__ dst_c, int H, long r0, long r1, int srcB) {
+  const long pieces = rowbytes / 16;
+  const long total = (r1 - r0) * pieces;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = r0 + i / pieces, p = i % pieces;
+    *(uint4*)(dst_xh + r * rowbytes + p * 16) = *(const uint4*)(src_xh + (r % srcB) * rowbytes + p * 16);
+  }
+  const long totc = (r1 - r0) * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < totc; i += (long)gridDim.x * blockDim.x) {
+    const long r = r0 + i / H;
+    dst_c[r * H + i % H] = src_c[(r % srcB) * H + i % H];
+  }
+}
+
 struct Ctx {
   int B, L, V, E, H, NL, dt;
   int din(int l) const { return l == 0 ? E : H; }
@@ -380,28 +397,49 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
   // up to a few hundred rows the per-step products are latency-bound: the fused step kernels; beyond that (Monte-Carlo
   // roll-out batches) they are large GEMMs and the generic 128-row-tile kernels are the efficient form
   static const int fused_max_rows = [] { const char* e = getenv("GIC_FUSED_ROLLOUT_MAX_ROWS"); return e ? atoi(e) : 512; }();
-  if (st->part && B <= fused_max_rows && decoder_step_supported(c.dt, V, E, H, NL))
+  if (st->part && B <= fused_max_rows && !(opt && opt->resume_from) && decoder_step_supported(c.dt, V, E, H, NL))
     return sample_fwd_fused<TA>(c, P, S, st, noise_u, seed, temperature, pretrain, out, ids, opt, stream);
   GIC_CHECK_ARG(st->logits && st->gpre, "decoder_sample_fwd: the unfused path needs state->logits and state->gpre");
   const bool keep = !(opt && opt->no_state);
   const int64_t* f_ids = opt ? opt->force_ids : nullptr;
   const int32_t* f_len = opt ? opt->force_len : nullptr;
+  // resumed roll-outs: at step t only the first act[t] rows exist; the rows that join take their state from the earlier call
+  const int32_t* act = (opt && opt->resume_from) ? opt->host_active_rows : nullptr;
+  if (act) GIC_PROPAGATE(hipMemcpyAsync(ids, f_ids, (size_t)B * L * sizeof(int64_t), hipMemcpyDeviceToDevice, stream) == hipSuccess ? GIC_OK : GIC_ERR_LAUNCH);
 
   for (int t = 0; t < L; ++t) {
+    const int M = act ? act[t] : B;                     // rows that take part in this step
+    if (act) {
+      const int M_prev = t > 0 ? act[t - 1] : 0;
+      if (M > M_prev) {
+        for (int l = 0; l < NL; ++l) {
+          const long rowbytes = c.ldx(l) * (long)c.asz();
+          const long work = (long)(M - M_prev) * (rowbytes / 16);
+          hipLaunchKernelGGL(rollout_join_kernel, dim3((unsigned)(work + 255) / 256 > 2048 ? 2048 : (unsigned)((work + 255) / 256)), dim3(256), 0, stream,
+                             (const unsigned char*)opt->resume_from->xh[l] + (size_t)t * opt->resume_B * rowbytes,
+                             (unsigned char*)st->xh[l] + (size_t)t * B * rowbytes, rowbytes,
+                             (const float*)(opt->resume_from->c[l] + (long)t * opt->resume_B * H), st->c[l] + (long)t * B * H, H,
+                             (long)M_prev, (long)M, opt->resume_B);
+          GIC_CHECK_LAUNCH("rollout_join");
+        }
+      }
+      if (M == 0) continue;
+    }
+    const int pw_grid_t = cdiv((long)M * H, 256);
     for (int l = 0; l < NL; ++l) {
       const long ld = c.ldx(l);
       TA* xh_t = (TA*)st->xh[l] + (long)t * B * ld;
       TA* xh_n = (TA*)st->xh[l] + (long)(t + 1) * B * ld;
       GemmDesc g;
       g.A = xh_t; g.lda = ld; g.B = S->wcat[l]; g.ldb = ld; g.C = st->gpre; g.ldc = 4 * H;
-      g.M = B; g.N = 4 * H; g.K = (int)ld; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.bias = S->bsum[l];
+      g.M = M; g.N = 4 * H; g.K = (int)ld; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.bias = S->bsum[l];
       GIC_PROPAGATE(gemm(g, stream));
       TA* h_up = (l + 1 < NL) ? (TA*)st->xh[l + 1] + (long)t * B * c.ldx(l + 1) : nullptr;
       TA* h_out = (l + 1 == NL && st->hout) ? (TA*)st->hout + (long)t * H : nullptr;
-      hipLaunchKernelGGL((lstm_pointwise_fwd_kernel<TA>), dim3(pw_grid), dim3(256), 0, stream,
+      hipLaunchKernelGGL((lstm_pointwise_fwd_kernel<TA>), dim3(pw_grid_t), dim3(256), 0, stream,
                          (const float*)st->gpre, (const float*)(st->c[l] + (long)t * B * H),
                          keep ? st->gates[l] + (long)t * B * 4 * H : (float*)nullptr, st->c[l] + (long)(t + 1) * B * H,
-                         xh_n + c.din(l), ld, h_up, h_up ? c.ldx(l + 1) : 0, h_out, (long)L * H, B, H);
+                         xh_n + c.din(l), ld, h_up, h_up ? c.ldx(l + 1) : 0, h_out, (long)L * H, M, H);
       GIC_CHECK_LAUNCH("lstm_pointwise_fwd");
     }
     {  // vocabulary projection on the last layer's h_t (lives in XH_last[t+1][:, Din:])
@@ -410,7 +448,7 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
       GemmDesc g;
       g.A = (TA*)st->xh[l] + (long)(t + 1) * B * ld + c.din(l); g.lda = ld;
       g.B = S->wout; g.ldb = H; g.C = st->logits; g.ldc = V;
-      g.M = B; g.N = V; g.K = H; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.bias = P->b_out;
+      g.M = M; g.N = V; g.K = H; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.bias = P->b_out;
       GIC_PROPAGATE(gemm(g, stream));
     }
     TA* x_next = (TA*)st->xh[0] + (long)(t + 1) * B * c.ldx(0);
@@ -418,15 +456,15 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
     TA* out_t = out ? (TA*)out + (long)t * V : nullptr;
     constexpr bool kFast = sizeof(TA) == 2;
     if (V % 4 == 0 && V <= 4096) {
-      hipLaunchKernelGGL((gumbel_softmax_argmax_reg_kernel<TA, 1, kFast>), dim3(B), dim3(1024), 0, stream, (const float*)st->logits,
+      hipLaunchKernelGGL((gumbel_softmax_argmax_reg_kernel<TA, 1, kFast>), dim3(M), dim3(1024), 0, stream, (const float*)st->logits,
                          u_t, seed, (uint64_t)t, temperature, pretrain, out_t, (long)L * V, ids + t, (long)L,
                          P->embed, x_next, c.ldx(0), V, E, f_ids ? f_ids + t : nullptr, f_len, t);
     } else if (V % 4 == 0 && V <= 16384) {
-      hipLaunchKernelGGL((gumbel_softmax_argmax_reg_kernel<TA, 4, kFast>), dim3(B), dim3(1024), 0, stream, (const float*)st->logits,
+      hipLaunchKernelGGL((gumbel_softmax_argmax_reg_kernel<TA, 4, kFast>), dim3(M), dim3(1024), 0, stream, (const float*)st->logits,
                          u_t, seed, (uint64_t)t, temperature, pretrain, out_t, (long)L * V, ids + t, (long)L,
                          P->embed, x_next, c.ldx(0), V, E, f_ids ? f_ids + t : nullptr, f_len, t);
     } else {
-      hipLaunchKernelGGL((gumbel_softmax_argmax_kernel<TA>), dim3(B), dim3(256), 0, stream, st->logits, u_t, seed, (uint64_t)t,
+      hipLaunchKernelGGL((gumbel_softmax_argmax_kernel<TA>), dim3(M), dim3(256), 0, stream, st->logits, u_t, seed, (uint64_t)t,
                          temperature, pretrain, out_t, (long)L * V, ids + t, (long)L, P->embed, x_next,
                          c.ldx(0), V, E, f_ids ? f_ids + t : nullptr, f_len, t);
     }
@@ -777,6 +815,15 @@ int gic_decoder_sample_fwd(const gic_decoder_dims* dims, const gic_decoder_param
   const bool keep = !(opt && opt->no_state);
   GIC_CHECK_ARG(!keep || (st->hout && out), "decoder_sample_fwd: out / state->hout may be NULL only for a stateless roll-out (opts->no_state)");
   GIC_CHECK_ARG(!(opt && opt->force_len && !opt->force_ids), "decoder_sample_fwd: force_len without force_ids");
+  if (opt && opt->resume_from) {
+    GIC_CHECK_ARG(opt->force_ids && opt->force_len && opt->host_active_rows && opt->resume_B > 0 && opt->no_state,
+                  "decoder_sample_fwd: resumed roll-outs need force_ids, force_len, host_active_rows, resume_B and no_state");
+    for (int l = 0; l < c.NL; ++l) GIC_CHECK_ARG(opt->resume_from->xh[l] && opt->resume_from->c[l], "decoder_sample_fwd: resume_from lacks layer %d state", l);
+    for (int t = 0; t < c.L; ++t)
+      GIC_CHECK_ARG(opt->host_active_rows[t] >= (t ? opt->host_active_rows[t - 1] : 0) && opt->host_active_rows[t] <= c.B,
+                    "decoder_sample_fwd: host_active_rows must be non-decreasing and <= B");
+    GIC_CHECK_ARG(opt->host_active_rows[0] == 0, "decoder_sample_fwd: resumed rows have a prefix of at least one token");
+  }
   for (int l = 0; l < c.NL; ++l)
     GIC_CHECK_ARG(st->xh[l] && (st->gates[l] || !keep) && st->c[l] && S->wcat[l] && S->bsum[l], "decoder_sample_fwd: null layer %d buffer", l);
   if (c.dt == DT_F32)

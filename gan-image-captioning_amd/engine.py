@@ -281,9 +281,11 @@ class DecoderEngine:
     def sample_fwd(self, params, features: torch.Tensor, Lc: int, temperature: float, pretrain: bool = False,
                    noise_u: Optional[torch.Tensor] = None, seed: int = 0, state=None, out=None, ids=None,
                    states=None, force_ids: Optional[torch.Tensor] = None, force_len: Optional[torch.Tensor] = None,
-                   ids_only: bool = False):
+                   ids_only: bool = False, resume=None):
         """``states`` = (h0, c0), each f32 [NL, B, H] (generator.py:55,61).  ``force_ids`` int64 [B, L] (+ ``force_len`` int32 [B]):
-        trajectory to follow (gicap.h).  ``ids_only``: inference roll-out, returns (None, ids, state) and saves nothing for backward."""
+        trajectory to follow (gicap.h).  ``ids_only``: inference roll-out, returns (None, ids, state) and saves nothing for backward.
+        ``resume`` = (state of an earlier call, its batch size, active_rows list[L]): resumed roll-outs (gicap.h,
+        gic_decoder_sample_opts.resume_from) -- rows sorted by prefix length, each starting at its prefix from that call's state."""
         self.check_params(params)
         require_gpu(features, noise_u, force_ids, force_len)
         B = features.shape[0]
@@ -326,6 +328,16 @@ class DecoderEngine:
                     opts.force_len = ptr(force_len)
                 keep += [force_ids, force_len]
             opts.no_state = int(bool(ids_only))
+        if resume is not None:
+            src_state, src_B, active = resume
+            if len(active) != Lc or force_ids is None or force_len is None or not ids_only or B <= 512:
+                raise ValueError("resumed roll-outs: active_rows per step, force_ids, force_len, ids_only and more than 512 rows")
+            src_struct = self._state_struct(src_state)
+            act = _arr(C.c_int32, Lc, [int(v) for v in active])
+            opts.resume_from = C.cast(C.pointer(src_struct), C.c_void_p)
+            opts.resume_B = int(src_B)
+            opts.host_active_rows = C.cast(act, C.c_void_p)
+            keep += [src_struct, act]
         d = self.dims(B, Lc)
         L.check(L.load().gic_decoder_sample_fwd(
             C.byref(d), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),

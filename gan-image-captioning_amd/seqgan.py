@@ -7,7 +7,8 @@ discriminator (src/discriminator.py:34-62) on token ids as the reward model.  De
 Kernel sequence (all through libgicap.so; buffers from PyTorch's allocator):
   1. Y ~ G                       gic_decoder_sample_fwd, ids only (categorical sampling = Gumbel-max at temperature 1)
   2. (L-1)*N*B roll-outs         ONE gic_decoder_sample_fwd call: rows follow their prefix (force_ids / force_len), then sample;
-                                 at this row count the per-step products are large MFMA GEMMs
+                                 at this row count the per-step products are large MFMA GEMMs, and a row starts at its prefix
+                                 length from the state of pass 4's forward (resume_from): half the row-steps
   3. rewards                     gic_disc_fwd on ids (eval mode) for all roll-outs and for Y, gic_rollout_rewards
   4. generator                   gic_decoder_sample_fwd along Y (logits, state kept) -> gic_xent with row weights = rewards (REINFORCE)
                                  -> gic_decoder_sample_bwd -> encoder head / start-token gradient -> clip + Adam
@@ -66,6 +67,8 @@ class SeqGANStep:
             feats = engine.embedding_fwd(gparams[0], ones)
         # 1. Y ~ G
         _, Y, _ = dec.sample_fwd(gparams, feats, L, 1.0, noise_u=u_sample, seed=0 if u_sample is not None else SEEDS.next(), ids_only=True)
+        # 4a. the generator's own pass along Y (logits; its recurrent state is kept: the roll-outs resume from it, the backward uses it)
+        logits, _, st = dec.sample_fwd(gparams, feats, L, 1.0, pretrain=True, force_ids=Y)
         # 2. + 3. roll-outs and rewards
         mc_logits = None
         reps = (L - 1) * N
@@ -73,14 +76,18 @@ class SeqGANStep:
             f_big = feats.repeat(reps, 1)
             force = Y.repeat(reps, 1)
             flen = torch.arange(1, L, device=dev, dtype=torch.int32).repeat_interleave(N * B)
+            resume = None
+            if reps * B > 512:
+                # generic-product path: a roll-out does not recompute its prefix, it starts at step t from pass 4a's state (rows are
+                # sorted by prefix length: at step t the first t*N*B rows exist) -- half the row-steps of the full batch
+                resume = (st, B, [min(t, L - 1) * N * B for t in range(L)])
             _, mc_ids, _ = dec.sample_fwd(gparams, f_big, L, 1.0, noise_u=u_mc, seed=0 if u_mc is not None else SEEDS.next(),
-                                          ids_only=True, force_ids=force, force_len=flen)
+                                          ids_only=True, force_ids=force, force_len=flen, resume=resume)
             mc_logits, _ = den.fwd(dparams, None, mc_ids, False)
         full_logits, _ = den.fwd(dparams, None, Y, False)
         rewards = engine.rollout_rewards(mc_logits, full_logits, B, L, N, R)
         out = {"ids": Y, "rewards": rewards}
-        # 4. REINFORCE
-        logits, _, st = dec.sample_fwd(gparams, feats, L, 1.0, pretrain=True, force_ids=Y)
+        # 4b. REINFORCE
         g_loss, dlog = engine.xent(logits.view(B * L, dec.V), Y.reshape(-1), want_grad=train, row_weight=rewards.reshape(-1))
         # 5. D on [real ; Y]
         km = keep_masks if keep_masks is not None else (None, None)

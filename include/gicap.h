@@ -140,6 +140,13 @@ typedef struct gic_decoder_sample_opts {
   const int32_t* force_len;              /* [B] number of leading steps that are forced per caption; NULL = all L */
   int32_t no_state;                      /* != 0: inference roll-out -- nothing is saved for a backward pass: state->gates / hout and
                                             `out` may be NULL (ids only) */
+  /* Resumed roll-outs (Monte-Carlo completions of prefixes of ONE sampled batch; generic-product path, i.e. more rows than the fused
+   * step kernels take): a row does not recompute its forced prefix.  Row r starts at step force_len[r] (>= 1) from the recurrent state
+   * that the call which filled `resume_from` (same weights; caption r % resume_B; the same forced tokens) had reached there.  Rows must
+   * be sorted by force_len ascending; host_active_rows[t] (HOST memory, L values) = number of rows with force_len <= t. */
+  const struct gic_decoder_state* resume_from;
+  int32_t resume_B;
+  const int32_t* host_active_rows;
 } gic_decoder_sample_opts;
 
 /* features [B,E] f32.  noise_u: explicit U[0,1) draws [L,B,V] f32 (generator.py:86-90 order) or NULL to

@@ -23,7 +23,7 @@ def _problem(B, L, V, E, H, NL, N, nf, seed):
     return gp, dp, caps, us, umc, masks
 
 
-@pytest.mark.parametrize("shape", [(4, 5, 52, 8, 16, 1, 3), (6, 6, 64, 16, 32, 2, 2)])
+@pytest.mark.parametrize("shape", [(4, 5, 52, 8, 16, 1, 3), (6, 6, 64, 16, 32, 2, 2), (8, 6, 64, 16, 32, 1, 14)])   # the last one: 560 roll-outs, resumed
 def test_seqgan_step_f32_matches_oracle(shape):
     from gan_image_captioning_amd.args import default_args
     from gan_image_captioning_amd.training import GANInstructor
@@ -93,6 +93,18 @@ def test_seqgan_rollouts_keep_their_prefix_and_run_at_scale():
     for t in range(1, L):
         assert torch.equal(mc[t - 1, :, :, :t], Yc[None, :, :t].expand(N, B, t)), f"prefix of length {t} not kept"
     assert len(torch.unique(mc[0].reshape(-1, L), dim=0)) > N * B // 2          # the completions actually differ
+    # resumed roll-outs (rows start at their prefix length from the state of a teacher-forced pass along Y) are the same roll-outs:
+    # same device noise (seed, row, step), so the completions agree except where bf16 rounding of the two routes to the prefix state
+    # (64-row fused kernels / 704-row products) flips a sample
+    _, _, st_y = dec.sample_fwd(gparams, feats, L, 1.0, pretrain=True, force_ids=Y)
+    _, mc2, _ = dec.sample_fwd(gparams, feats.repeat(reps, 1), L, 1.0, seed=12, ids_only=True, force_ids=Y.repeat(reps, 1), force_len=flen,
+                               resume=(st_y, B, [min(t, L - 1) * N * B for t in range(L)]))
+    torch.cuda.synchronize()
+    mc2 = mc2.view(L - 1, N, B, L).cpu()
+    for t in range(1, L):
+        assert torch.equal(mc2[t - 1, :, :, :t], Yc[None, :, :t].expand(N, B, t)), f"resumed: prefix of length {t} not kept"
+    agree = float((mc2 == mc).float().mean())
+    assert agree > 0.9, agree
     before = inst.gen_arena.flat.clone(), inst.disc_arena.flat.clone()
     losses = inst.adv_step(None, caps, L, train=True)
     torch.cuda.synchronize()
