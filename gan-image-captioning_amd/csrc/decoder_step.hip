@@ -20,6 +20,16 @@ typedef const __attribute__((address_space(1))) f32x4* gptr_f4;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+#ifdef GIC_STAMPS
+}  // anon
+__device__ unsigned long long g_dstamp[2][2][8][2];      // [lstm_step | vocab_step][first | last block][phase][shader clock, 100 MHz real time]
+namespace {
+#define DSTAMP(kn, i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) { \
+  unsigned long long* p_ = g_dstamp[kn][blockIdx.x == 0 ? 0 : 1][i]; p_[0] = __builtin_amdgcn_s_memtime(); p_[1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define DSTAMP(kn, i) do {} while (0)
+#endif
+
 template <typename TA> struct Frag;
 template <> struct Frag<bf16_t> { bf16x8 v; };
 template <> struct Frag<float> { float v[8]; };
@@ -104,14 +114,14 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
   }
 }
 
-// 16 bytes of the compute-dtype image of an f32 master row (embedding gather): 8 values in bf16, 4 in f32
-template <typename TA> __device__ __forceinline__ u32x4 chunk_from_f32(const float* p);
-template <> __device__ __forceinline__ u32x4 chunk_from_f32<float>(const float* p) { return *(gptr_u4)p; }
-template <> __device__ __forceinline__ u32x4 chunk_from_f32<bf16_t>(const float* p) {
-  const f32x4 a = *(gptr_f4)p, b = *(gptr_f4)(p + 4);
+// 16 bytes of the compute-dtype image of an f32 master row (embedding gather) from its raw 16-byte loads: 8 values in bf16 (two
+// loads), 4 in f32 (one).  Loading and converting are separate: a thread has every load of a pass in flight before it touches one.
+template <typename TA> __device__ __forceinline__ u32x4 pack_f32_chunk(const f32x4& lo, const f32x4& hi);
+template <> __device__ __forceinline__ u32x4 pack_f32_chunk<float>(const f32x4& lo, const f32x4& hi) { return __builtin_bit_cast(u32x4, lo); }
+template <> __device__ __forceinline__ u32x4 pack_f32_chunk<bf16_t>(const f32x4& lo, const f32x4& hi) {
   bf16x8 v;
-  v[0] = (bf16_t)a[0]; v[1] = (bf16_t)a[1]; v[2] = (bf16_t)a[2]; v[3] = (bf16_t)a[3];
-  v[4] = (bf16_t)b[0]; v[5] = (bf16_t)b[1]; v[6] = (bf16_t)b[2]; v[7] = (bf16_t)b[3];
+  v[0] = (bf16_t)lo[0]; v[1] = (bf16_t)lo[1]; v[2] = (bf16_t)lo[2]; v[3] = (bf16_t)lo[3];
+  v[4] = (bf16_t)hi[0]; v[5] = (bf16_t)hi[1]; v[6] = (bf16_t)hi[2]; v[7] = (bf16_t)hi[3];
   return __builtin_bit_cast(u32x4, v);
 }
 
@@ -135,6 +145,7 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmStepArgs a, co
   const int lr = lane & 15, lg = lane >> 4;
   const int j0 = blockIdx.x * kUnitsPerBlock;
   const int b0 = blockIdx.y * kStepRows;
+  DSTAMP(0, 0);
 
   if (a.gather) {
     // next-input token of each row: the forced trajectory, else the first maximal index of the previous step's logits
@@ -153,6 +164,7 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmStepArgs a, co
     __syncthreads();
   }
 
+  DSTAMP(0, 1);
   const TA* xh = (const TA*)a.xh_t;
   const int ju = j0 + (lr & 3);                       // B-operand row lr = gate (lr >> 2), unit (lr & 3)
   const bool jok = ju < a.H;
@@ -173,41 +185,85 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmStepArgs a, co
   for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int ldx = (int)a.ldx;
   const int gw = a.gw ? a.gw : a.din;
-  for (int kc0 = 0; kc0 < ldx; kc0 += KC) {
-    const int kc = min(KC, ldx - kc0);
-    if (kc0) __syncthreads();                          // every wave has read the previous chunk
-    // ---- this wave's weight fragments of the chunk (k-steps w, w+8, ...: at most 4 for KC <= 1024), straight from L2
+  // Every block of the launch stages the SAME activation rows: walked in the same order they would all ask one L2 channel for the
+  // same lines at the same moment (measured: 7.4 us of a 10.5 us block for 192 KB).  Blocks sharing an XCD (blockIdx % 8) start at
+  // different rows, so that at any instant their requests fall on different channels.
+  const int rot = ((blockIdx.x >> 3) * 4 + (blockIdx.x & 7)) & (kStepRows - 1);
+  // One K chunk.  Written as a lambda that the common single-chunk / single-pass shape calls in STRAIGHT-LINE code: inside a loop the
+  // compiler's wait-count bookkeeping merges the back edge's pending loads into the loop head and waits for everything outstanding
+  // (the bias / cell-state loads, then the weight fragments) before it issues the staging loads -- two extra serial round trips.
+  auto chunk = [&](const int kc0, const int kc) {
+    // ---- this wave's weight fragments of the chunk (k-steps w, w+8, ...: at most 4 for KC <= 1024), straight from L2; k-steps past
+    // the chunk re-read its last one (their activation fragments are zero).  Issued from inside the first staging pass.
     Frag<TA> fb[4];
+    auto load_weights = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int kl = (w + 8 * i) * 32 + lg * 8;
-      fb[i] = zero_frag<TA>();
-      if (kl < kc && jok && !(a.dbg & 1)) fb[i] = load_frag<TA>(wrow + kc0 + kl);
-    }
-    // ---- stage the activation chunk [64, kc]: 8 independent 16-byte pieces per thread in flight, then the LDS writes
-    const int cpr = kc / VE;                           // 16-byte pieces per row (kc % 8 == 0)
-    const int total = kStepRows * cpr;
-    for (int c0 = 0; c0 < total; c0 += 8 * 512) {
-      u32x4 v[8];
+      for (int i = 0; i < 4; ++i) fb[i] = load_frag<TA>(wrow + kc0 + min((w + 8 * i) * 32 + lg * 8, kc - 8));
+    };
+    // ---- stage the activation chunk [64, kc]: the leading `xc` columns of a gathering step come from the f32 embedding rows of the
+    // rows' tokens, the rest from [x_t | h_{t-1}].  Per pass a thread has 8 + 8 pieces in flight: UNCONDITIONAL loads from clamped
+    // addresses (a predicated or branch-wrapped load makes the compiler wait for each piece in turn: measured 16 serial round trips,
+    // 15k cycles), piece coordinates by increments (one integer division per thread and range), then conversions and LDS writes.
+    // Rows past B repeat row B-1 (their results are never stored).
+    if (!(a.dbg & 2)) {
+      const int xc = a.gather ? max(0, min(kc, gw - kc0)) : 0;      // gw % 8 == 0: a 16-byte piece never straddles x | rest
+      const int rlast = a.B - 1 - b0;                                // last valid tile row (>= 0: the grid covers B)
+      const int cprx = xc / VE, totx = kStepRows * cprx;             // embedding columns [0, xc)
+      const int cprh = (kc - xc) / VE, toth = kStepRows * cprh;      // activation columns [xc, kc)
+      int rowx = 0, ccx = 0, drowx = 0, dccx = 0, rowh = 0, cch = 0, drowh = 0, dcch = 0;
+      if (totx) { rowx = tid / cprx; ccx = tid % cprx; drowx = 512 / cprx; dccx = 512 % cprx; }
+      if (toth) { rowh = tid / cprh; cch = tid % cprh; drowh = 512 / cprh; dcch = 512 % cprh; }
+      auto pass = [&](const int c0) {
+        const bool dox = c0 < totx, doh = c0 < toth;                 // block-uniform
+        u32x4 lo[8], hi[8], v[8];
+        int prx[8], pcx[8], prh[8], pch[8];
+        if (dox) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = c0 + i * 512 + tid;
-        const int row = c / cpr, cc = c - row * cpr;
-        const int k = kc0 + cc * VE;
-        v[i] = (u32x4){0u, 0u, 0u, 0u};
-        if (c < total && b0 + row < a.B && !(a.dbg & 2)) {
-          if (a.gather && k < gw) v[i] = chunk_from_f32<TA>(a.embed + (long)ids_s[row] * gw + k);   // gw % 8 == 0: never straddles x | rest
-          else v[i] = *(gptr_u4)(xh + (long)(b0 + row) * a.ldx + k);
+          for (int i = 0; i < 8; ++i) {
+            prx[i] = rowx; pcx[i] = ccx;
+            const int r = min((rowx + rot) & (kStepRows - 1), rlast);
+            const float* src = a.embed + (long)ids_s[r] * gw + kc0 + ccx * VE;
+            lo[i] = *(gptr_u4)src;
+            if (SZ == 2) hi[i] = *(gptr_u4)(src + 4);
+            rowx += drowx; ccx += dccx;
+            if (ccx >= cprx) { ccx -= cprx; ++rowx; }
+            if (rowx >= kStepRows) rowx = kStepRows - 1;             // pieces past the end re-read the last row (not written)
+          }
         }
-      }
+        if (doh) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = c0 + i * 512 + tid;
-        const int row = c / cpr, cc = c - row * cpr;
-        if (c < total) *(u32x4*)(sA + row * hs + cc * 16) = v[i];
-      }
+          for (int i = 0; i < 8; ++i) {
+            prh[i] = rowh; pch[i] = cch;
+            const int r = min((rowh + rot) & (kStepRows - 1), rlast);
+            v[i] = *(gptr_u4)(xh + (long)(b0 + r) * a.ldx + kc0 + xc + cch * VE);
+            rowh += drowh; cch += dcch;
+            if (cch >= cprh) { cch -= cprh; ++rowh; }
+            if (rowh >= kStepRows) rowh = kStepRows - 1;
+          }
+        }
+        if (c0 == 0) load_weights();                                 // behind the staging loads: nothing waits for them but the MFMAs
+        if (dox) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            u32x4 x = lo[i];
+            if (SZ == 2) x = pack_f32_chunk<TA>(__builtin_bit_cast(f32x4, lo[i]), __builtin_bit_cast(f32x4, hi[i]));
+            if (c0 + i * 512 + tid < totx) *(u32x4*)(sA + ((prx[i] + rot) & (kStepRows - 1)) * hs + pcx[i] * 16) = x;
+          }
+        }
+        if (doh) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (c0 + i * 512 + tid < toth) *(u32x4*)(sA + ((prh[i] + rot) & (kStepRows - 1)) * hs + xc * SZ + pch[i] * 16) = v[i];
+        }
+      };
+      if (totx <= 8 * 512 && toth <= 8 * 512) pass(0);
+      else for (int c0 = 0; c0 < totx || c0 < toth; c0 += 8 * 512) pass(c0);
+    } else {
+      load_weights();
     }
+    DSTAMP(0, 2);
     __syncthreads();
+    DSTAMP(0, 3);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int kl = (w + 8 * i) * 32 + lg * 8;
@@ -220,7 +276,14 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmStepArgs a, co
         }
       }
     }
-  }
+  };
+  if (ldx <= KC) chunk(0, ldx);
+  else
+    for (int kc0 = 0; kc0 < ldx; kc0 += KC) {
+      if (kc0) __syncthreads();                          // every wave has read the previous chunk
+      chunk(kc0, min(KC, ldx - kc0));
+    }
+  DSTAMP(0, 4);
   __syncthreads();                                       // the staging area becomes the reduction buffer
   float (*red)[kStepRows][17] = (float (*)[kStepRows][17])ls_smem;
 #pragma unroll
@@ -228,6 +291,7 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmStepArgs a, co
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[w][mt * 16 + lg * 4 + r][lr] = acc[mt][r];
   __syncthreads();
+  DSTAMP(0, 5);
 
   if (pok) {
     const int rb = tid >> 2, u = tid & 3;
@@ -254,6 +318,7 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmStepArgs a, co
     if (a.h_up) ((TA*)a.h_up)[(long)b * a.ld_up + j] = hv;
     if (a.h_out) ((TA*)a.h_out)[(long)b * a.ld_out + j] = hv;
   }
+  DSTAMP(0, 6);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -282,6 +347,7 @@ __global__ __launch_bounds__(512) void vocab_step_kernel(const VocabStepArgs a, 
   const int lr = lane & 15, lg = lane >> 4;
   const int mt = w >> 1, kh = w & 1;
   const int v0 = blockIdx.x * kVocabTile, b0 = blockIdx.y * kStepRows;
+  DSTAMP(1, 0);
 
   // ---- epilogue operands that depend on nothing computed here: requested now
   const int vq = v0 + mt * 16 + lg * 4;
@@ -300,54 +366,78 @@ __global__ __launch_bounds__(512) void vocab_step_kernel(const VocabStepArgs a, 
   f32x4 acc[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int rot = ((blockIdx.x >> 3) * 4 + (blockIdx.x & 7)) & (kStepRows - 1);     // h_t is every block's: see lstm_step
   const TA* Wg = (const TA*)a.wout;
   const TA* Hg = (const TA*)a.h;
   for (int kc0 = 0; kc0 < H; kc0 += KC) {
     const int kc = min(KC, H - kc0);
     if (kc0) __syncthreads();
-    // ---- stage W_out[v0:v0+64, kc0:kc0+kc] and h_t[b0:b0+64, kc0:kc0+kc]: up to 8 + 8 pieces per thread in flight per pass
-    const int cpr = kc / VE;
+    // ---- stage W_out[v0:v0+64, kc0:kc0+kc] and h_t[b0:b0+64, kc0:kc0+kc]: 8 + 8 pieces per thread in flight per pass, unconditional
+    // loads from clamped addresses and piece coordinates by increments (see lstm_step).  Vocabulary rows past V and batch rows past
+    // B repeat the last valid one (their results are masked / never stored); a K tail (columns kc .. kc32) is staged as ZEROS.
+    const int kc32 = (kc + 31) & ~31;
+    const int cpr = kc32 / VE;
     const int total = kStepRows * cpr;
-    for (int c0 = 0; c0 < total; c0 += 8 * 512) {
-      u32x4 vw[8], vh[8];
+    if (!(a.dbg & 4)) {
+      const int drow = 512 / cpr, dcc = 512 % cpr;
+      const int wlast = V - 1 - v0, hlast = a.B - 1 - b0, cclast = kc / VE - 1;
+      int row = tid / cpr, cc = tid % cpr;
+      for (int c0 = 0; c0 < total; c0 += 8 * 512) {
+        u32x4 vw[8], vh[8];
+        int prow[8], pcc[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = c0 + i * 512 + tid;
-        const int row = c / cpr, cc = c - row * cpr;
-        vw[i] = (u32x4){0u, 0u, 0u, 0u};
-        vh[i] = (u32x4){0u, 0u, 0u, 0u};
-        if (c < total) {
-          if (v0 + row < V && !(a.dbg & 1)) vw[i] = *(gptr_u4)(Wg + (long)(v0 + row) * H + kc0 + cc * VE);
-          if (b0 + row < a.B && !(a.dbg & 4)) vh[i] = *(gptr_u4)(Hg + (long)(b0 + row) * a.ldh + kc0 + cc * VE);
+        for (int i = 0; i < 8; ++i) {
+          prow[i] = row; pcc[i] = cc;
+          const int ccl = min(cc, cclast);
+          const int hrow = (row + rot) & (kStepRows - 1);
+          vw[i] = *(gptr_u4)(Wg + (long)(v0 + min(row, wlast)) * H + kc0 + ccl * VE);
+          vh[i] = *(gptr_u4)(Hg + (long)(b0 + min(hrow, hlast)) * a.ldh + kc0 + ccl * VE);
+          row += drow; cc += dcc;
+          if (cc >= cpr) { cc -= cpr; ++row; }
+          if (row >= kStepRows) row = kStepRows - 1;           // pieces past the end re-read the last row (not written)
         }
-      }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = c0 + i * 512 + tid;
-        const int row = c / cpr, cc = c - row * cpr;
-        if (c < total) {
-          *(u32x4*)(sW + row * hs + cc * 16) = vw[i];
-          *(u32x4*)(sH + row * hs + cc * 16) = vh[i];
+        for (int i = 0; i < 8; ++i) {
+          const bool tail = pcc[i] > cclast;
+          if (tail) vw[i] = vh[i] = (u32x4){0u, 0u, 0u, 0u};
+          if (c0 + i * 512 + tid < total) {
+            *(u32x4*)(sW + prow[i] * hs + pcc[i] * 16) = vw[i];
+            *(u32x4*)(sH + ((prow[i] + rot) & (kStepRows - 1)) * hs + pcc[i] * 16) = vh[i];
+          }
         }
       }
     }
+    DSTAMP(1, 1);
     __syncthreads();
+    DSTAMP(1, 2);
     // ---- products: the chunk's k-steps split in two contiguous halves
     const int nks = (kc + 31) >> 5;
     const int half0 = (nks + 1) >> 1;
     const int ks_lo = kh ? half0 : 0, ks_hi = kh ? nks : half0;
-    for (int ks = ks_lo; ks < ks_hi && !(a.dbg & 2); ++ks) {
-      const int kl = ks * 32 + lg * 8;
-      Frag<TA> fa = zero_frag<TA>();
-      if (kl < kc) fa = lds_frag<TA>(sW + (mt * 16 + lr) * hs + kl * SZ);
+    // (the K tail is zero in LDS: unconditional fragment reads, the next k-step's five in flight under this one's MFMAs)
+    if (!(a.dbg & 2) && ks_lo < ks_hi) {
+      const unsigned char* pa = sW + (mt * 16 + lr) * hs + lg * 8 * SZ;
+      const unsigned char* pb = sH + lr * hs + lg * 8 * SZ;
+      Frag<TA> fa = lds_frag<TA>(pa + ks_lo * 32 * SZ), fb[4];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        Frag<TA> fb = zero_frag<TA>();
-        if (kl < kc) fb = lds_frag<TA>(sH + (nt * 16 + lr) * hs + kl * SZ);
-        mma<TA>(acc[nt], fa, fb);
+      for (int nt = 0; nt < 4; ++nt) fb[nt] = lds_frag<TA>(pb + nt * 16 * hs + ks_lo * 32 * SZ);
+      for (int ks = ks_lo; ks < ks_hi; ++ks) {
+        const int kn = (ks + 1 < ks_hi ? ks + 1 : ks) * 32 * SZ;      // the last iteration re-reads its own step (discarded)
+        const Frag<TA> fa_n = lds_frag<TA>(pa + kn);
+        Frag<TA> fb_n[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) fb_n[nt] = lds_frag<TA>(pb + nt * 16 * hs + kn);
+        __builtin_amdgcn_sched_barrier(0);                             // (the scheduler would sink the reads to their uses)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) mma<TA>(acc[nt], fa, fb[nt]);
+        __builtin_amdgcn_sched_barrier(0);
+        fa = fa_n;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) fb[nt] = fb_n[nt];
       }
     }
   }
+  DSTAMP(1, 3);
   __syncthreads();                                         // staging area -> exchange / reduction scratch
 
   // ---- K halves: wave (mt, kh) keeps batch sub-tiles 2kh, 2kh+1 and receives the partner's partial sums for them
@@ -370,6 +460,7 @@ __global__ __launch_bounds__(512) void vocab_step_kernel(const VocabStepArgs a, 
     for (int r = 0; r < 4; ++r) own[i][r] += p[r];
   }
 
+  DSTAMP(1, 4);
   // ---- epilogue: lane = batch row b0 + 16 nt + lr, vocabulary entries vq .. vq+3
   const float bia[4] = {bias4[0], bias4[1], bias4[2], bias4[3]};
   const float eps = 1e-10f;                                // generator.py:84
@@ -422,6 +513,7 @@ __global__ __launch_bounds__(512) void vocab_step_kernel(const VocabStepArgs a, 
     if (lg == 0) { red_y[mt * kStepRows + (2 * kh + i) * 16 + lr] = bv; red_i[mt * kStepRows + (2 * kh + i) * 16 + lr] = bi; }
   }
   __syncthreads();
+  DSTAMP(1, 5);
   float e[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -446,6 +538,7 @@ __global__ __launch_bounds__(512) void vocab_step_kernel(const VocabStepArgs a, 
     }
   }
   __syncthreads();
+  DSTAMP(1, 6);
   if (tid < kStepRows && b0 + tid < a.B) {
     float m = red_y[tid], s = red_s[tid];
     int bi = red_i[tid];
@@ -460,6 +553,7 @@ __global__ __launch_bounds__(512) void vocab_step_kernel(const VocabStepArgs a, 
     a.part_s[o] = s;
     atomicMax(a.rowkey + b0 + tid, row_key(m, bi));
   }
+  DSTAMP(1, 7);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -674,3 +768,8 @@ int sample_finish(const SampleFinishArgs& a, int dtype, hipStream_t stream) {
 }
 
 }  // namespace gic
+#ifdef GIC_STAMPS
+extern "C" int gic_debug_decoder_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gic::g_dstamp), sizeof(unsigned long long) * 2 * 2 * 8 * 2);
+}
+#endif
