@@ -609,6 +609,18 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(const LstmBwdStepArg
   const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
   const int K = 4 * a.H;
   const bool bok = b0 + lr < a.B, jok = j0 + lr < a.H;
+  // operands of the pointwise stage (threads 0..255: row tid >> 4, unit tid & 15): requested now, consumed after the products
+  const int pb = b0 + (tid >> 4), pj = j0 + (tid & 15);
+  const bool pok = tid < 256 && pb < a.B && pj < a.H;
+  const long pbh = (long)(pok ? pb : 0) * a.H + (pok ? pj : 0);
+  float p_dh = 0.f, p_g[4] = {0.f, 0.f, 0.f, 0.f}, p_cc = 0.f, p_cp = 0.f, p_dc = 0.f;
+  if (pok) {
+    if (a.dh_above) p_dh = a.dh_above[(long)pb * a.ld_above + pj];
+    if (a.dh_extra) p_dh += a.dh_extra[pbh];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) p_g[g] = a.gates[(long)pb * K + g * a.H + pj];
+    p_cc = a.c_cur[pbh]; p_cp = a.c_prev[pbh]; p_dc = a.dc_state[pbh];
+  }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int nks = (K + 31) >> 5;
 #pragma unroll
@@ -621,40 +633,36 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(const LstmBwdStepArg
     for (int ks0 = w * KPI; ks0 < nks; ks0 += 8 * KPI) {
       Frag<TA> fa[KPI], fb[KPI];
 #pragma unroll
-      for (int i = 0; i < KPI; ++i) {
-        const int k = (ks0 + i) * 32 + lg * 8;
-        fa[i] = zero_frag<TA>();
-        fb[i] = zero_frag<TA>();
-        if (k < K && bok) fa[i] = load_frag<TA>(arow + k);
-        if (k < K && jok) fb[i] = load_frag<TA>(wrow + k);
+      for (int i = 0; i < KPI; ++i) {        // unconditional loads from clamped addresses: all 2 KPI of them in flight
+        const int k = min((ks0 + i) * 32 + lg * 8, K - 8);
+        fa[i] = load_frag<TA>(arow + k);
+        fb[i] = load_frag<TA>(wrow + k);
       }
 #pragma unroll
-      for (int i = 0; i < KPI; ++i) mma<TA>(acc, fa[i], fb[i]);
+      for (int i = 0; i < KPI; ++i) {
+        if ((ks0 + i) * 32 + lg * 8 >= K) fa[i] = zero_frag<TA>();       // k-steps past K (rows / units past the end are never stored)
+        mma<TA>(acc, fa[i], fb[i]);
+      }
     }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[w][lg * 4 + r][lr] = acc[r];
   __syncthreads();
-  if (tid < 256) {
+  if (pok) {
     const int rb = tid >> 4, u = tid & 15;
-    const int b = b0 + rb, j = j0 + u;
-    if (b < a.B && j < a.H) {
-      float dh = a.dh_above ? a.dh_above[(long)b * a.ld_above + j] : 0.f;
-      if (a.dh_extra) dh += a.dh_extra[(long)b * a.H + j];
+    const int j = pj;
+    float dh = p_dh;
 #pragma unroll
-      for (int ww = 0; ww < 8; ++ww) dh += red[ww][rb][u];
-      const float* g = a.gates + (long)b * K;
-      const float i_ = g[j], f_ = g[a.H + j], g_ = g[2 * a.H + j], o_ = g[3 * a.H + j];
-      const long bh = (long)b * a.H + j;
-      const float tc = tanhf(a.c_cur[bh]);
-      const float dc = a.dc_state[bh] + dh * o_ * (1.f - tc * tc);
-      TA* dg = (TA*)a.dgates + (long)b * K;
-      dg[j] = from_f32<TA>(dc * g_ * i_ * (1.f - i_));
-      dg[a.H + j] = from_f32<TA>(dc * a.c_prev[bh] * f_ * (1.f - f_));
-      dg[2 * a.H + j] = from_f32<TA>(dc * i_ * (1.f - g_ * g_));
-      dg[3 * a.H + j] = from_f32<TA>(dh * tc * o_ * (1.f - o_));
-      a.dc_state[bh] = dc * f_;
-    }
+    for (int ww = 0; ww < 8; ++ww) dh += red[ww][rb][u];
+    const float i_ = p_g[0], f_ = p_g[1], g_ = p_g[2], o_ = p_g[3];
+    const float tc = tanhf(p_cc);
+    const float dc = p_dc + dh * o_ * (1.f - tc * tc);
+    TA* dg = (TA*)a.dgates + (long)pb * K;
+    dg[j] = from_f32<TA>(dc * g_ * i_ * (1.f - i_));
+    dg[a.H + j] = from_f32<TA>(dc * p_cp * f_ * (1.f - f_));
+    dg[2 * a.H + j] = from_f32<TA>(dc * i_ * (1.f - g_ * g_));
+    dg[3 * a.H + j] = from_f32<TA>(dh * tc * o_ * (1.f - o_));
+    a.dc_state[pbh] = dc * f_;
   }
 }
 

@@ -68,10 +68,29 @@ struct BnSrc {            // y-side or residual-side BatchNorm inputs; stats == 
 __device__ __forceinline__ void bn_coeffs(const BnSrc& b, int c, int C, float inv_count, float& scale, float& shift) {
   float mean, var;
   if (b.stats) {
+    // the replicas' loads are independent: eight pairs in flight per round trip (a load / add loop waits for each replica in turn;
+    // replicas past nrep re-read the last one with weight 0)
+    const float g = b.gamma[c], bt = b.beta[c];
     float s1 = 0.f, s2 = 0.f;
-    for (int r = 0; r < b.nrep; ++r) { s1 += b.stats[(long)r * 2 * C + c]; s2 += b.stats[(long)r * 2 * C + C + c]; }
+    for (int r0 = 0; r0 < b.nrep; r0 += 8) {
+      float a[8], q[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const long rr = min(r0 + r, b.nrep - 1);
+        a[r] = b.stats[rr * 2 * C + c];
+        q[r] = b.stats[rr * 2 * C + C + c];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float wgt = r0 + r < b.nrep ? 1.f : 0.f;
+        s1 += wgt * a[r]; s2 += wgt * q[r];
+      }
+    }
     mean = s1 * inv_count;
     var = fmaxf(s2 * inv_count - mean * mean, 0.f);
+    scale = g * rsqrtf(var + kBnEps);
+    shift = bt - mean * scale;
+    return;
   } else if (b.run_mean) {
     mean = b.run_mean[c]; var = b.run_var[c];
   } else { scale = 1.f; shift = 0.f; return; }
@@ -93,52 +112,49 @@ __device__ __forceinline__ void stage_coeffs(float* coef, const BnSrc& b, int C,
 template <typename TA> struct Vec16 { static constexpr int N = 16 / sizeof(TA); };
 
 // ---- out = [relu]( bn(y) + (res ? bn_res(res) : 0) ), rows x C; 16 bytes (8 bf16 / 4 f32 channels) per access
-template <typename TA>
+template <typename TA, bool RES>
 __global__ __launch_bounds__(1024) void bn_act_kernel(const TA* __restrict__ y, BnSrc by, const TA* __restrict__ res, BnSrc br,
                                                       float inv_count, int relu, TA* __restrict__ out, long rows, int C) {
   extern __shared__ __attribute__((aligned(16))) float coef[];      // [4][C]
   constexpr int VN = Vec16<TA>::N;
   stage_coeffs(coef, by, C, inv_count);
-  if (res) stage_coeffs(coef + 2 * C, br, C, inv_count);
+  if (RES) stage_coeffs(coef + 2 * C, br, C, inv_count);
   __syncthreads();
   const int cv = C / VN;
-  const long total = rows * cv;
-  // gridDim.x*256 is a multiple of cv (both powers of two, launch code), so a thread keeps one channel group for all
-  // its rows: its coefficients move from LDS to registers once and the loop is pure load / fma / store.
+  // gridDim.x*1024 is a multiple of cv (launch code), so a thread keeps one channel group for all its rows: its coefficients move
+  // from LDS to registers once, its element offsets advance by a constant, and the loop is pure load / fma / store.
   const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c0 = (int)(i0 % cv) * VN;
   float sc[VN], sh[VN], rs[VN], rh[VN];
 #pragma unroll
   for (int k = 0; k < VN; ++k) {
     sc[k] = coef[c0 + k]; sh[k] = coef[C + c0 + k];
-    rs[k] = res ? coef[2 * C + c0 + k] : 0.f; rh[k] = res ? coef[3 * C + c0 + k] : 0.f;
+    rs[k] = RES ? coef[2 * C + c0 + k] : 0.f; rh[k] = RES ? coef[3 * C + c0 + k] : 0.f;
   }
-  // 4 independent 16-byte loads in flight per thread (rows i, i+S, i+2S, i+3S) before any arithmetic
-  const long S = (long)gridDim.x * blockDim.x;
-  for (long i = i0; i < total; i += 4 * S) {
+  // 4 (+4) independent 16-byte loads in flight per thread (rows r, r+R, r+2R, r+3R) before any arithmetic; the loads are
+  // unconditional (rows past the end re-read the thread's first row: nothing waits between them), the stores are not
+  const long R = (long)gridDim.x * blockDim.x / cv;
+  for (long r = i0 / cv; r < rows; r += 4 * R) {
     TA yv[4][VN], rv[4][VN];
     long o[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const long iu = i + u * S;
-      o[u] = (iu / cv) * C + c0;
-      if (iu < total) {
-        *(uint4*)yv[u] = *(const uint4*)(y + o[u]);
-        if (res) *(uint4*)rv[u] = *(const uint4*)(res + o[u]);
-      }
+      const long ru = r + u * R;
+      o[u] = (ru < rows ? ru : r) * C + c0;
+      *(uint4*)yv[u] = *(const uint4*)(y + o[u]);
+      if (RES) *(uint4*)rv[u] = *(const uint4*)(res + o[u]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (i + u * S >= total) break;
       TA ov[VN];
 #pragma unroll
       for (int k = 0; k < VN; ++k) {
         float v = to_f32<TA>(yv[u][k]) * sc[k] + sh[k];
-        if (res) v += to_f32<TA>(rv[u][k]) * rs[k] + rh[k];
+        if (RES) v += to_f32<TA>(rv[u][k]) * rs[k] + rh[k];
         if (relu) v = fmaxf(v, 0.f);
         ov[k] = from_f32<TA>(v);
       }
-      *(uint4*)(out + o[u]) = *(const uint4*)ov;
+      if (r + u * R < rows) *(uint4*)(out + o[u]) = *(const uint4*)ov;
     }
   }
 }
@@ -412,12 +428,22 @@ int gic_bn_act(const void* y, const float* stats, const float* gamma, const floa
   const BnSrc br = make_src(res_stats, stats_nrep, res_gamma, res_beta, res_run_mean, res_run_var);
   GIC_CHECK_ARG(C % 8 == 0 && (C & (C - 1)) == 0, "bn_act: C must be a power of two >= 8 (got %d)", C);
   const size_t lds = (size_t)4 * C * sizeof(float);
+  const int cv = C / (dtype == DT_F32 ? 4 : 8);
+  const long total = rows * cv;
+  int grid = bn_act_grid(total);
+  {  // threads keep their channel group: grid * 1024 must be a multiple of cv (it is for every power-of-two C)
+    int step = cv, t = 1024;
+    while (t) { const int m = step % t; step = t; t = m; }       // step = gcd(cv, 1024)
+    const int mult = cv / step;
+    grid = (grid + mult - 1) / mult * mult;
+  }
+  const hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_F32) {
-    const long total = rows * (C / 4);
-    hipLaunchKernelGGL((bn_act_kernel<float>), dim3(bn_act_grid(total)), dim3(1024), lds, (hipStream_t)stream, (const float*)y, by, (const float*)res, br, 1.f / count, relu, (float*)out, (long)rows, C);
+    if (res) hipLaunchKernelGGL((bn_act_kernel<float, true>), dim3(grid), dim3(1024), lds, st, (const float*)y, by, (const float*)res, br, 1.f / count, relu, (float*)out, (long)rows, C);
+    else hipLaunchKernelGGL((bn_act_kernel<float, false>), dim3(grid), dim3(1024), lds, st, (const float*)y, by, (const float*)res, br, 1.f / count, relu, (float*)out, (long)rows, C);
   } else {
-    const long total = rows * (C / 8);
-    hipLaunchKernelGGL((bn_act_kernel<bf16_t>), dim3(bn_act_grid(total)), dim3(1024), lds, (hipStream_t)stream, (const bf16_t*)y, by, (const bf16_t*)res, br, 1.f / count, relu, (bf16_t*)out, (long)rows, C);
+    if (res) hipLaunchKernelGGL((bn_act_kernel<bf16_t, true>), dim3(grid), dim3(1024), lds, st, (const bf16_t*)y, by, (const bf16_t*)res, br, 1.f / count, relu, (bf16_t*)out, (long)rows, C);
+    else hipLaunchKernelGGL((bn_act_kernel<bf16_t, false>), dim3(grid), dim3(1024), lds, st, (const bf16_t*)y, by, (const bf16_t*)res, br, 1.f / count, relu, (bf16_t*)out, (long)rows, C);
   }
   GIC_CHECK_LAUNCH("bn_act");
   return GIC_OK;

@@ -40,6 +40,26 @@ namespace {
 #define DBG 0
 #endif
 
+// Sum / sum of squares of channel c over the replicas of a BatchNorm statistics arena [nrep][2][C]: eight independent pairs of loads
+// in flight per round trip (a load / add loop waits for each replica in turn); replicas past nrep re-read the last one with weight 0.
+__device__ __forceinline__ void fold_replicas(const float* stats, int nrep, int C, int c, float& s1, float& s2) {
+  s1 = s2 = 0.f;
+  for (int r0 = 0; r0 < nrep; r0 += 8) {
+    float a[8], q[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const long rr = min(r0 + r, nrep - 1);
+      a[r] = stats[rr * 2 * C + c];
+      q[r] = stats[rr * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float wgt = r0 + r < nrep ? 1.f : 0.f;
+      s1 += wgt * a[r]; s2 += wgt * q[r];
+    }
+  }
+}
+
 template <typename T> struct GlobalPtr { typedef const __attribute__((address_space(1))) T* type; };
 
 // PIPE (k-contiguous, vectorised operands only): tiles reach LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPR
@@ -640,8 +660,8 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
     for (int c = tid; c < ABN_MAXK; c += NT) {
       float sc = 0.f, sh = 0.f;
       if (c < Cn) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int r = 0; r < d.in_nrep; ++r) { s1 += d.in_stats[(long)r * 2 * Cn + c]; s2 += d.in_stats[(long)r * 2 * Cn + Cn + c]; }
+        float s1, s2;
+        fold_replicas(d.in_stats, d.in_nrep, Cn, c, s1, s2);
         const float mean = s1 * d.in_inv_count;
         const float var = fmaxf(s2 * d.in_inv_count - mean * mean, 0.f);
         sc = d.in_gamma[c] * rsqrtf(var + 1e-5f);              // kBnEps of encoder.hip (nn.BatchNorm2d default)
@@ -651,8 +671,8 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
       if constexpr (ARES) {      // the shortcut: its own BatchNorm (projection) or identity (scale 1, shift 0)
         float rs = 1.f, rt = 0.f;
         if (d.res_stats && c < Cn) {
-          float s1 = 0.f, s2 = 0.f;
-          for (int r = 0; r < d.res_nrep; ++r) { s1 += d.res_stats[(long)r * 2 * Cn + c]; s2 += d.res_stats[(long)r * 2 * Cn + Cn + c]; }
+          float s1, s2;
+          fold_replicas(d.res_stats, d.res_nrep, Cn, c, s1, s2);
           const float mean = s1 * d.res_inv_count;
           const float var = fmaxf(s2 * d.res_inv_count - mean * mean, 0.f);
           rs = d.res_gamma[c] * rsqrtf(var + 1e-5f);
