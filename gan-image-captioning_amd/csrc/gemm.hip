@@ -12,6 +12,7 @@
 // Both: XCD-aware block -> tile map (each of the 8 XCDs owns a contiguous run of tiles that share B panels in its L2), C tile
 // staged through LDS for 16-byte row stores, BatchNorm column sums folded across the block in the epilogue.
 #include "gemm.h"
+#include "conv3x3.h"
 
 #include <stdlib.h>
 
@@ -1190,6 +1191,12 @@ int pick_layout(const GemmDesc& d, bool vec, hipStream_t stream) {
 
 template <typename TI, typename TO, int EPI>
 int pick_conv(const GemmDesc& d, hipStream_t stream) {
+  if constexpr (sizeof(TI) == 2 && sizeof(TO) == 2 && EPI == EPI_BNSTATS) {
+    // 3x3 / stride 1: the input patch stays in LDS for all nine taps (conv3x3.hip).  BatchNorm on load of any other window than
+    // 1x1 exists there only (tile8 would re-normalise the tile once per tap: slower than the separate pass it replaces).
+    if (try_conv3x3_patch(d, stream)) { GIC_CHECK_LAUNCH("conv3x3 patch"); return GIC_OK; }
+    if (d.in_stats && d.cKH * d.cKW > 1) return GIC_ERR_UNSUPPORTED;
+  }
   if constexpr (sizeof(TI) == 2) {
     if (try_tile8<TO, EPI, true>(d, stream)) { GIC_CHECK_LAUNCH("conv tile8"); return GIC_OK; }
   }

@@ -358,8 +358,7 @@ class TrunkPlan:
             if blk["kind"] == "basic":
                 flush()
                 self._conv(c1, x, e["y1"], stats, N, hin, hin)
-                self._bn_act(c1, e["y1"], e["z1"], stats, training, rows[c1.name])
-                self._conv(c2, e["z1"], e["y2"], stats, N, ho, ho)
+                self._bn_relu_conv(c1, e["y1"], e["z1"], c2, e["y2"], stats, training, N, ho, ho, rows[c1.name])
                 last, ylast = c2, e["y2"]
             else:
                 # conv1: if the previous block's output is pending, it is formed on load (bn3 + shortcut + relu) and written by the
@@ -368,10 +367,9 @@ class TrunkPlan:
                     flush()
                     self._conv(c1, x, e["y1"], stats, N, hin, hin)
                 pend = None
-                # measured: riding bn1 into the 3x3 convolution's A path costs more than the bn_act it saves (the tile is rewritten
-                # once per tap); the 1x1 consumer below is where it pays
-                self._bn_act(c1, e["y1"], e["z1"], stats, training, rows[c1.name])
-                self._conv(c2, e["z1"], e["y2"], stats, N, hin, hin)
+                # bn1 + ReLU ride into the 3x3 convolution where its input patch stays in LDS (stride 1: normalised once per chunk,
+                # not once per tap; the library declines the stride-2 ones: bn_act + plain convolution), bn2 + ReLU into conv3
+                self._bn_relu_conv(c1, e["y1"], e["z1"], c2, e["y2"], stats, training, N, hin, hin, rows[c1.name])
                 self._bn_relu_conv(c2, e["y2"], e["z2"], c3, e["y3"], stats, training, N, ho, ho, rows[c2.name])
                 last, ylast = c3, e["y3"]
             if ds is not None:
@@ -417,7 +415,7 @@ class TrunkPlan:
             c1, c2, c3, ds = blk["c1"], blk["c2"], blk["c3"], blk["ds"]
             hin, ho = e["hin"], e["hout"]
             seq = [(c1, x, e["y1"], hin, ("res", pend) if (pend is not None and c1.fused_in) else None),
-                   (c2, e["z1"], e["y2"], ho if blk["kind"] == "basic" else hin, None)]
+                   (c2, e["z1"], e["y2"], ho if blk["kind"] == "basic" else hin, (c1, e["y1"], b["rows"][c1.name]))]
             if c3 is not None:
                 seq.append((c3, e["z2"], e["y3"], ho, (c2, e["y2"], b["rows"][c2.name])))
             if ds is not None:

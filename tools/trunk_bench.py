@@ -18,3 +18,6 @@ for _ in range(20):
     trunk(x, 1)
 b.record(); b.synchronize()
 print(f"trunk forward alone: {a.elapsed_time(b) / 20 * 1e3:.1f} us")
+plan = trunk._plan
+print("conv2 with bn1 on load:", sum(1 for blk in plan.blocks if blk["c2"].fused_in), "of", len(plan.blocks),
+      "| conv3 with bn2 on load:", sum(1 for blk in plan.blocks if blk["c3"] is not None and blk["c3"].fused_in))
