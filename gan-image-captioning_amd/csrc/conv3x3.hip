@@ -61,6 +61,13 @@ __device__ __forceinline__ void fold_replicas(const float* stats, int nrep, int 
   }
 }
 
+// Which of the 16 pixels of a fragment's segment MFMA row x holds.  ds_read_b128 serves a wave in groups of lanes {0-3, 12-15,
+// 20-27}, ...: rows 0-3 and 12-15 of one 16-byte channel chunk together with rows 4-11 of the NEXT chunk.  With pixel p's chunk c
+// stored at slot c ^ ((p >> 1) & 7) of its 128 bytes, such a group is conflict-free for every tap (every shift of the segment inside
+// the patch) iff rows 4-11 hold the pixels of one parity and rows 0-3, 12-15 those of the other (consecutive rows measured 23-44 %
+// of the LDS cycles as bank conflicts: the tap offset moves the segment off the alignment the XOR pattern assumes).
+__device__ __forceinline__ int frag_row(int x) { return x < 4 ? 2 * x + 1 : (x < 12 ? 2 * (x - 4) : 2 * (x - 12) + 9); }
+
 // a / b for 0 <= a < 2^23, b > 0 with inv = 1.f / b: a float product and one correction step instead of the ~40-instruction integer
 // division (a workgroup needs a dozen of them before it can issue its first DMA: measured 1.2-1.8 us of its 6.6 us at 56x56)
 __device__ __forceinline__ int fdiv(int a, int b, float inv) {
@@ -181,11 +188,11 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchDesc d) {
   issue_b(0, 0, 0);
   issue_b(1, 0, 1);
 
-  // fragment rows of this lane: output pixels bm0 + wr*32 + t*16 + lr -> patch pixel of tap (0, 0)
+  // fragment rows of this lane: output pixels bm0 + wr*32 + t*16 + frag_row(lr) -> patch pixel of tap (0, 0)
   int pbase[TM];
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
-    const int m = min(bm0 + wr * 32 + t * 16 + lr, mlim - 1);           // rows past the tile repeat its last pixel (never stored)
+    const int m = min(bm0 + wr * 32 + t * 16 + frag_row(lr), mlim - 1); // rows past the tile repeat its last pixel (never stored)
     const int n = fdiv(m, HW, iHW), rem = m - n * HW;
     const int ho = fdiv(rem, W, iW), wo = rem - ho * W;
     pbase[t] = (n * PH + ho - gp0) * PW + wo;
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchDesc d) {
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ml = wr * 32 + i * 16 + lg * 4 + r;
+        const int ml = wr * 32 + i * 16 + frag_row(lg * 4 + r);
         const float v = acc[i][j][r];
         *(bf16_t*)(sC + ml * SC + nl * 2) = (bf16_t)v;
         if (bm0 + ml < mlim) { st_s += v; st_q += v * v; }

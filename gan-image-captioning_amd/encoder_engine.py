@@ -530,8 +530,8 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None, 
     use_ms = step_ms if step_ms > 0 else total_ms
     achieved = total_flops / (use_ms * 1e-3) / 1e12
     fmt = lambda l: {"layer": l[1], "cin": l[2][0], "cout": l[2][1], "k": l[2][2], "stride": l[2][3], "tflops": round(l[0], 1), "us": round(l[3] * 1e3, 1)}
-    return {"kernel": "conv kernels of the ResNet trunk (tile8_kernel<CONV, EPI_BNSTATS> family): implicit-GEMM convolution, bf16 16x16x32 MFMA, 8 waves, "
-                      f"LDS-DMA ring, {launches} launches/step",
+    return {"kernel": "conv kernels of the ResNet trunk (tile8_kernel<CONV, EPI_BNSTATS> implicit GEMM; conv3x3_patch_kernel for the 3x3 / stride-1 layers, "
+                      f"input patch resident in LDS): bf16 16x16x32 MFMA, 8 waves, LDS-DMA ring, {launches} launches/step",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(achieved / peak_tflops, 4),
             "measured": ("HIP events around every convolution launch on its launch stream while the train step runs on the other streams, "
                          "minus the per-layer bracket overhead (bracket with the chip idle - back-to-back replay)"
