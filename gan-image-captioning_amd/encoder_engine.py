@@ -95,7 +95,7 @@ class TrunkPlan:
         self.fuse_in = not os.environ.get("GIC_NO_FUSED_BN_IN")
         # block outputs formed on load by the next conv1 (gic_conv1x1_res_in): opt-in.  Measured at cfg2 it takes 0.31 ms of bn_act out of
         # the step and adds 0.20 ms to seven conv1 launches (step 3.18 -> 3.14 ms, within run-to-run noise): see DESIGN.md section 4
-        self.fuse_res = bool(os.environ.get("GIC_FUSED_RES_IN"))
+        self.fuse_res = os.environ.get("GIC_FUSED_RES_IN", "1") != "0"     # block outputs formed on load by the next conv1 (large grids)
         self.res_min_rows = int(os.environ.get("GIC_RES_IN_MIN_ROWS", "50000"))
         self._nrep = {}
         self.use_graph = not os.environ.get("GIC_NO_GRAPH")
