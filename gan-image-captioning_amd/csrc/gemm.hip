@@ -13,6 +13,7 @@
 // staged through LDS for 16-byte row stores, BatchNorm column sums folded across the block in the epilogue.
 #include "gemm.h"
 #include "conv3x3.h"
+#include "conv1x1_stream.h"
 
 #include <stdlib.h>
 
@@ -1195,6 +1196,8 @@ int pick_conv(const GemmDesc& d, hipStream_t stream) {
     // 3x3 / stride 1: the input patch stays in LDS for all nine taps (conv3x3.hip).  BatchNorm on load of any other window than
     // 1x1 exists there only (tile8 would re-normalise the tile once per tap: slower than the separate pass it replaces).
     if (try_conv3x3_patch(d, stream)) { GIC_CHECK_LAUNCH("conv3x3 patch"); return GIC_OK; }
+    // shallow 1x1 layers over many rows: persistent workgroups, resident weights, A tiles streamed across row tiles (conv1x1_stream.hip)
+    if (try_conv1x1_stream(d, stream)) { GIC_CHECK_LAUNCH("conv1x1 stream"); return GIC_OK; }
     if (d.in_stats && d.cKH * d.cKW > 1) return GIC_ERR_UNSUPPORTED;
   }
   if constexpr (sizeof(TI) == 2) {
