@@ -346,9 +346,48 @@ int sample_fwd_fused(const Ctx& c, const gic_decoder_params* P, const gic_decode
   float* part_m = st->part;
   float* part_s = st->part + per;
   unsigned long long* rowkey = (unsigned long long*)(st->part + ((2 * per + 1) & ~1l));      // [L][B], 8-byte aligned
-  GIC_PROPAGATE(fill_zero(rowkey, (size_t)L * B * sizeof(unsigned long long), stream));    // atomicMax targets start below every key
+  unsigned int* sync = (unsigned int*)(rowkey + (long)L * B);                                // [2] persistent kernel: barrier counter, error flag
+  // atomicMax targets start below every key; the sync words start at zero
+  GIC_PROPAGATE(fill_zero(rowkey, (size_t)L * B * sizeof(unsigned long long) + 2 * sizeof(unsigned int), stream));
   const bool keep = !(opt && opt->no_state);
-  for (int t = 0; t < L; ++t) {
+  const bool persistent = rollout_persistent_supported(c.dt, B, V, c.E, H, NL);
+  if (persistent) {
+    // ONE launch for all L steps (decoder_step.h): the arguments of step 0 and the strides between steps
+    const long ld = c.ldx(0);
+    RolloutArgs r;
+    LstmStepArgs& a = r.l0;
+    a.xh_t = st->xh[0]; a.xh_next = (TA*)st->xh[0] + (long)B * ld;
+    a.wcat = S->wcat[0]; a.bsum = S->bsum[0];
+    a.c_prev = st->c[0]; a.c_new = st->c[0] + (long)B * H;
+    a.gates = keep ? st->gates[0] : nullptr;
+    if (st->hout) { a.h_out = st->hout; a.ld_out = (long)L * H; }
+    a.B = B; a.H = H; a.din = c.din(0); a.ldx = ld;
+    a.embed = P->embed; a.V = V;
+    if (opt && opt->force_ids) { a.force_ids = opt->force_ids; a.force_stride = L; a.force_len = opt->force_len; }
+    VocabStepArgs& v = r.v0;
+    v.h = (TA*)st->xh[0] + (long)B * ld + c.din(0); v.ldh = ld;
+    v.wout = S->wout; v.bias = P->b_out;
+    v.u = noise_u;
+    v.seed = seed; v.rng_stream = 0; v.temperature = temperature; v.pretrain = pretrain;
+    v.out = out; v.out_stride = (long)L * V;
+    v.part_m = part_m; v.part_s = part_s; v.rowkey = rowkey;
+    v.nblk = nblk; v.B = B; v.V = V; v.H = H;
+    r.L = L;
+    r.xh_step = (long)B * ld * (long)sizeof(TA);
+    r.c_step = (long)B * H;
+    r.gates_step = (long)B * 4 * H;
+    r.hout_step = (long)H * (long)sizeof(TA);
+    r.out_step = (long)V * (long)sizeof(TA);
+    r.part_step = (long)B * nblk;
+    r.u_step = (long)B * V;
+    r.rowkey0 = rowkey;
+    r.sync = sync;
+    const int by = cdiv(B, kStepRows);
+    r.grid_lx = cdiv(H, kUnitsPerBlock); r.grid_l = r.grid_lx * by;
+    r.grid_vx = nblk; r.grid_v = nblk * by;
+    GIC_PROPAGATE(rollout_persistent(r, c.dt, stream));
+  }
+  for (int t = 0; t < L && !persistent; ++t) {
     for (int l = 0; l < NL; ++l) {
       const long ld = c.ldx(l);
       LstmStepArgs a;
@@ -384,6 +423,7 @@ int sample_fwd_fused(const Ctx& c, const gic_decoder_params* P, const gic_decode
   f.pretrain = pretrain; f.out = out; f.ids = ids;
   if (opt && opt->force_ids) { f.force_ids = opt->force_ids; f.force_len = opt->force_len; }
   if (keep) { f.embed = P->embed; f.xh0 = st->xh[0]; f.ldx0 = c.ldx(0); }
+  if (persistent) f.err = sync + 1;
   return sample_finish(f, c.dt, stream);
 }
 

@@ -499,17 +499,20 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None, 
         key = (s.cin, s.cout, s.k, s.stride, H, mode + (10 if (mode == 2 and prev[1][3] is not None) else 0))
         if key not in seen:
             seen[key] = [event_time_ms(lambda: plan.replay(s, xi, yo, b["stats"], N, H, W, kw, prev), 5, stream), 0, macs,
-                         s.name + {0: "", 1: " [bn+relu on load]", 2: " [block output on load]", 12: " [block output on load, proj.]"}[key[5]], 0.0]
+                         s.name + {0: "", 1: " [bn+relu on load]", 2: " [block output on load]", 12: " [block output on load, proj.]"}[key[5]], 0.0,
+                         # the same layer as a plain convolution of an already normalised input (what the fused launches replaced)
+                         event_time_ms(lambda: plan.replay(s, xi, yo, b["stats"], N, H, W, kw, None), 5, stream) if mode else None]
         seen[key][1] += 1
         if in_step and s.name in in_step["in_step"]:
             v, a0 = in_step["in_step"][s.name], in_step["alone"].get(s.name)
             overhead = max(0.0, sum(a0) / len(a0) - seen[key][0]) if a0 else 0.0
             seen[key][4] += max(seen[key][0], sum(v) / len(v) - overhead)
-    total_ms = total_flops = bound_us = total_bytes = step_ms = 0.0
+    total_ms = total_flops = bound_us = total_bytes = step_ms = plain_ms = 0.0
     launches = 0
     layers = []
-    for key, (ms, count, macs, name, ms_step) in seen.items():
+    for key, (ms, count, macs, name, ms_step, ms_plain) in seen.items():
         total_ms += ms * count
+        plain_ms += (ms if ms_plain is None else ms_plain) * count
         step_ms += ms_step
         total_flops += 2.0 * macs * count
         launches += count
@@ -517,6 +520,8 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None, 
         layers.append((tf, name, key, ms, count))
         Ho = (key[4] + 2 * (key[2] // 2) - key[2]) // key[3] + 1
         nbytes = 2.0 * (N * key[4] * key[4] * key[0] + N * Ho * Ho * key[1] + key[0] * key[1] * key[2] * key[2])
+        if key[5] in (2, 12):          # block output formed on load: + the shortcut tensor read and the block output written back
+            nbytes += 2.0 * 2 * N * key[4] * key[4] * key[0]
         floor_us = max(2.0 * macs / (peak_tflops * 1e12), nbytes / 8e12) * 1e6
         bound_us += floor_us * count
         total_bytes += nbytes * count
@@ -526,6 +531,7 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None, 
     print(f"[conv] all {launches} launches: isolated {total_ms * 1e3:.1f} us, in-step {step_ms * 1e3:.1f} us; per-layer max(MFMA, HBM) floor {bound_us:.1f} us",
           file=sys.stderr)
     layers.sort()
+    plain = total_flops / (plain_ms * 1e-3) / 1e12
     iso = total_flops / (total_ms * 1e-3) / 1e12
     use_ms = step_ms if step_ms > 0 else total_ms
     achieved = total_flops / (use_ms * 1e-3) / 1e12
@@ -542,4 +548,7 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None, 
             "floor_ms_per_step": round(bound_us / 1e3, 4),      # sum over layers of max(flops / MFMA peak, bytes / 8 TB/s)
             "frac_of_floor": round(bound_us / 1e3 / use_ms, 4),
             "isolated_replay": {"ms_per_step": round(total_ms, 4), "achieved": round(iso, 2), "frac": round(iso / peak_tflops, 4)},
+            # every layer as a plain convolution (input already normalised, block outputs materialised by bn_act): the kernels' own
+            # quality, independent of how much BatchNorm / residual work rides in the launches
+            "plain_conv_variant": {"ms_per_step": round(plain_ms, 4), "achieved": round(plain, 2), "frac": round(plain / peak_tflops, 4)},
             "slowest_layer": fmt(layers[0]), "fastest_layer": fmt(layers[-1])}

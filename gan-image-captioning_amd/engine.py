@@ -236,8 +236,9 @@ class DecoderEngine:
         }
 
     def part_floats(self, B: int, Lc: int) -> int:
-        """Floats of the fused step kernels' scratch: [2][L][B][ceil(V/64)] tile partials + [L][B] 64-bit argmax keys (gicap.h)."""
-        return 2 * Lc * B * ((self.V + 63) // 64) + 2 * Lc * B + 2
+        """Floats of the fused step kernels' scratch: [2][L][B][ceil(V/64)] tile partials + [L][B] 64-bit argmax keys + the persistent
+        roll-out kernel's two sync words (gicap.h; = gic_decoder_state_bytes' figure)."""
+        return 2 * Lc * B * ((self.V + 63) // 64) + 2 * Lc * B + 4
 
     def alloc_rollout_state(self, B: int, Lc: int, dev) -> Dict[str, object]:
         """State of an inference roll-out (``no_state``): recurrent buffers only, nothing saved for a backward pass."""
