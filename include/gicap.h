@@ -379,10 +379,11 @@ int gic_conv2d(const void* in, const void* w, void* out, float* stats, int stats
 /* Convolution whose INPUT is normalised on the fly: out = conv(pad(relu(gamma (in - mean) / sqrt(var + 1e-5) + beta))) with
  * mean / var from `in_stats` ([in_nrep][2*Cin] sums written by the gic_conv2d that produced `in`, over in_count rows).  Replaces the
  * bn -> ReLU -> conv links inside the torchvision residual blocks (src/generator.py:12-14) without the separate gic_bn_act pass
- * and without the normalised tensor: the kernel rewrites each A tile in LDS before its MFMAs (padding taps stay zero).  `stats`
- * receives this convolution's own column sums as gic_conv2d does.  Returns GIC_STATUS_UNSUPPORTED (and launches nothing) in f32
- * mode, for Cin > 1024 or Cin % 8 != 0, or for shapes the 8-wave kernel does not take: the caller then runs gic_bn_act +
- * gic_conv2d. */
+ * and without the normalised tensor: 1x1 windows rewrite each A tile in LDS before its MFMAs; 3x3 / stride 1 / pad 1 windows with
+ * Cin % 64 == 0 keep the input patch of a 128-pixel tile in LDS for all nine taps and normalise it once per 64-channel chunk
+ * (padding stays zero).  `stats` receives this convolution's own column sums as gic_conv2d does.  Returns GIC_STATUS_UNSUPPORTED
+ * (and launches nothing) in f32 mode, for Cin > 1024 or Cin % 8 != 0, for any other window, or for shapes the kernels do not
+ * take: the caller then runs gic_bn_act + gic_conv2d. */
 int gic_conv2d_bn_in(const void* in, const float* in_stats, int in_nrep, const float* in_gamma, const float* in_beta, float in_count,
                      const void* w, void* out, float* stats, int stats_nrep, int dtype, int N, int H, int W, int Cin, int Cout, int KH,
                      int KW, int stride, int pad, void* stream);
