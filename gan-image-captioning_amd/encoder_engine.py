@@ -97,6 +97,7 @@ class TrunkPlan:
         # the step and adds 0.20 ms to seven conv1 launches (step 3.18 -> 3.14 ms, within run-to-run noise): see DESIGN.md section 4
         self.fuse_res = os.environ.get("GIC_FUSED_RES_IN", "1") != "0"     # block outputs formed on load by the next conv1 (large grids)
         self.res_min_rows = int(os.environ.get("GIC_RES_IN_MIN_ROWS", "50000"))
+        self.res_max_cout = int(os.environ.get("GIC_RES_IN_MAX_COUT", "128"))
         self._nrep = {}
         self.use_graph = not os.environ.get("GIC_NO_GRAPH")
         self.pending_tracked = 0
@@ -242,7 +243,8 @@ class TrunkPlan:
         last, ylast, res, res_step, rows, out = pend
         # measured (profiles/, cfg2): the fused launch beats bn_act + plain convolution where the grid is large (>= ~390 row tiles: the
         # 56x56 and 28x28 inputs at batch 64: -8..-15 us per block); on small grids the ring-less fused kernel is latency-bound
-        if c1.fused_in is False or c1.k != 1 or c1.stride != 1 or rows < self.res_min_rows:
+        # ... and where conv1 has ONE output-channel tile: every further tile would fetch and form the two A-side tiles again
+        if c1.fused_in is False or c1.k != 1 or c1.stride != 1 or rows < self.res_min_rows or c1.cout > self.res_max_cout:
             return False
         base = stats.data_ptr()
         rs = base + 4 * res_step.stats_off if res_step is not None else None

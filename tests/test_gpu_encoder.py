@@ -59,6 +59,8 @@ CONV_CASES = [  # (N, Cin, H, Cout, k, stride, pad)
     # the streaming shallow-K 1x1 kernel (conv1x1_stream.hip; >= 1024 output tiles): K = 64 with a ragged 64-wide channel tile and a
     # row tail, K = 64 / 256 output channels, K = 128 / 512 output channels
     (41, 64, 56, 96, 1, 1, 0), (40, 64, 56, 256, 1, 1, 0), (44, 128, 28, 512, 1, 1, 0),
+    # the A-panel-resident 1x1 kernel (conv1x1_panel.hip; K = 256, >= 512 output channels): a row tail, groups of channel tiles
+    (5, 256, 14, 1024, 1, 1, 0), (64, 256, 14, 512, 1, 1, 0),
 ]
 
 
@@ -324,7 +326,8 @@ def test_block_output_formed_on_load_equals_the_separate_pass(dev):
         trunk(images, 1)                                   # builds the plan
         plan = trunk._plan
         plan.fuse_res = fused
-        plan.res_min_rows = 0                              # every eligible block (the production plan fuses the large grids only)
+        plan.res_min_rows = 0                              # every eligible block (the production plan fuses the large grids with a
+        plan.res_max_cout = 1 << 20                        # single output-channel tile only)
         plan.use_graph = False
         for s in plan.steps:
             s.fused_in = None                              # re-probe
@@ -384,7 +387,8 @@ def test_cold_and_mispredicted_trunk_passes_do_not_race_the_lookahead(dev):
 @pytest.mark.parametrize("case", [(8, 28, 128, 512, 1, 1, 0), (4, 56, 64, 256, 1, 1, 0), (16, 14, 256, 1024, 1, 1, 0), (2, 7, 512, 2048, 1, 1, 0),
                                   (3, 9, 72, 40, 1, 1, 0), (4, 28, 128, 128, 3, 1, 1), (4, 28, 128, 128, 3, 2, 1), (8, 56, 64, 64, 3, 1, 1),
                                   (16, 14, 256, 256, 3, 1, 1), (8, 7, 512, 512, 3, 1, 1), (2, 12, 192, 96, 3, 1, 1),
-                                  (40, 56, 64, 256, 1, 1, 0), (44, 28, 128, 512, 1, 1, 0), (41, 56, 64, 96, 1, 1, 0)])
+                                  (40, 56, 64, 256, 1, 1, 0), (44, 28, 128, 512, 1, 1, 0), (41, 56, 64, 96, 1, 1, 0),
+                                  (5, 14, 256, 1024, 1, 1, 0), (64, 14, 256, 1024, 1, 1, 0)])
 def test_conv_with_input_batchnorm_equals_bn_act_then_conv(dev, case):
     """gic_conv2d_bn_in (bn + ReLU applied to the A tiles in LDS, padding taps left at zero) against gic_bn_act followed by
     gic_conv2d on the same raw tensor and statistics: same bf16 input to the MFMAs, so outputs and column sums agree to rounding."""
