@@ -133,6 +133,77 @@ __global__ __launch_bounds__(256) void disc_conv_pool_fwd_kernel(const float* __
   }
 }
 
+// ---- the same on the matrix cores (s == 1, filter widths <= 8): v_mfma_f32_16x16x4_f32 -- fp32 products and accumulation, so both
+// compute modes keep the fp32 convolution of the reference.  One workgroup = 16 (caption, representation) pairs; per filter tile (16
+// filters of one width) and time step t one MFMA (two for widths 5..8) forms D[pair][filter] = bias + sum_j x[pair][t + j] w[filter][j]:
+//   A[pair][k] = x[pair][t + k]   (lane: pair = lane & 15, k = lane >> 4; one LDS read)
+//   B[k][filter] = w[filter][k]   (lane: filter = lane & 15, k = lane >> 4; held in registers across t)
+//   C = bias[filter]              (every row of the accumulator tile)
+// then relu, running max and first-index argmax per (pair, filter) in registers (discriminator.py:42,45).  The scalar kernel above
+// re-reads every filter's weights per pair (57 MB of L2 traffic per launch at cfg2) and reaches 14 TFLOP/s: 35 us for 0.5 GFLOP.
+template <typename TA>
+__global__ __launch_bounds__(512) void disc_conv_pool_fwd_mfma_kernel(const float* __restrict__ emb, ConvMeta cm, int L, int De, int R, long rowsBR,
+                                                                        TA* __restrict__ pooled, uint8_t* __restrict__ argmax) {
+  __shared__ float xs[16][265];                                  // [pair][t], zero beyond L (L <= 255, + 8 taps of padding; odd stride: banks)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const long br0 = (long)blockIdx.x * 16;
+  for (int i = tid; i < 16 * 264; i += 512) {
+    const int p = i / 264, t = i - p * 264;
+    const long br = br0 + p;
+    float v = 0.f;
+    if (br < rowsBR && t < L) v = emb[((br / R) * L + t) * De + (br % R)];       // s == 1: representation r reads embedding column r
+    xs[p][t] = v;
+  }
+  __syncthreads();
+  // filter tiles: for each width k, ceil(nfilt / 16) tiles of 16 filters; waves take them round robin
+  int tile = 0;
+  for (int k = 0; k < cm.nconv; ++k) {
+    const int f = cm.fsize[k], nf = cm.nfilt[k], T = L - f + 1;
+    const float* wk = cm.w[k];
+    const float* bk = cm.b[k];
+    for (int c0 = 0; c0 < nf; c0 += 16, ++tile) {
+      if ((tile & 7) != w) continue;                             // wave-uniform
+      const int ch = c0 + li;
+      const bool ok = ch < nf;
+      // B fragments: taps lk and 4 + lk of filter ch (zero beyond the width / the filter count)
+      const float b0 = (ok && lk < f) ? wk[(long)ch * f + lk] : 0.f;
+      const float b1 = (ok && 4 + lk < f) ? wk[(long)ch * f + 4 + lk] : 0.f;
+      const float bias = ok ? bk[ch] : 0.f;
+      float best[4] = {-1.f, -1.f, -1.f, -1.f};
+      int bt[4] = {0, 0, 0, 0};
+      for (int t = 0; t < T; ++t) {
+        f32x4 acc = {bias, bias, bias, bias};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[li][t + lk], b0, acc, 0, 0, 0);
+        if (f > 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[li][t + 4 + lk], b1, acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = fmaxf(acc[r], 0.f);                    // relu then max over time, first index on ties
+          if (v > best[r]) { best[r] = v; bt[r] = t; }
+        }
+      }
+      // accumulator row 4 lk + r = pair, column li = filter
+      if (ok) {
+        const int col = cm.foff[k] + ch;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long br = br0 + 4 * lk + r;
+          if (br < rowsBR) {
+            pooled[br * cm.Fp + col] = from_f32<TA>(best[r]);
+            argmax[br * cm.Fp + col] = (uint8_t)bt[r];
+          }
+        }
+      }
+    }
+  }
+  // pad columns F .. Fp-1 (zero, argmax 0: as the scalar kernel writes them)
+  for (int i = tid; i < 16 * (cm.Fp - cm.F); i += 512) {
+    const int p = i / (cm.Fp - cm.F), c = cm.F + i % (cm.Fp - cm.F);
+    const long br = br0 + p;
+    if (br < rowsBR) { pooled[br * cm.Fp + c] = from_f32<TA>(0.f); argmax[br * cm.Fp + c] = 0; }
+  }
+}
+
 // ---- conv backward, input side: d emb.  One block per (b, r) owns its s embedding columns.
 template <typename TA>
 __global__ __launch_bounds__(256) void disc_conv_pool_bwd_x_kernel(const float* __restrict__ dpooled, const TA* __restrict__ pooled,
@@ -403,7 +474,11 @@ int disc_fwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
   // 2. conv + relu + max over time
   int max_taps = 0;
   for (int k = 0; k < c.cm.nconv; ++k) max_taps = c.cm.fsize[k] * c.s > max_taps ? c.cm.fsize[k] * c.s : max_taps;
-  if (max_taps <= 8)
+  static const bool no_mfma = getenv("GIC_NO_DISC_CONV_MFMA") != nullptr;
+  if (c.s == 1 && max_taps <= 8 && !no_mfma)
+    hipLaunchKernelGGL((disc_conv_pool_fwd_mfma_kernel<TA>), dim3((unsigned)((c.rowsBR + 15) / 16)), dim3(512), 0, stream,
+                       (const float*)st->emb, c.cm, c.L, c.De, c.R, c.rowsBR, (TA*)st->pooled, st->argmax);
+  else if (max_taps <= 8)
     hipLaunchKernelGGL((disc_conv_pool_fwd_kernel<TA, 8>), dim3((unsigned)c.rowsBR), dim3(256), c.L * c.s * sizeof(float), stream,
                        (const float*)st->emb, c.cm, c.L, c.De, c.R, (TA*)st->pooled, st->argmax);
   else
