@@ -144,12 +144,12 @@ __global__ __launch_bounds__(256) void disc_conv_pool_fwd_kernel(const float* __
 template <typename TA>
 __global__ __launch_bounds__(512) void disc_conv_pool_fwd_mfma_kernel(const float* __restrict__ emb, ConvMeta cm, int L, int De, int R, long rowsBR,
                                                                         TA* __restrict__ pooled, uint8_t* __restrict__ argmax) {
-  __shared__ float xs[16][265];                                  // [pair][t], zero beyond L (L <= 255, + 8 taps of padding; odd stride: banks)
+  __shared__ float xs[16][269];                                  // [pair][t], zero beyond L (L <= 255, + the taps and the 4-step blocks' overhang; odd stride: banks)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const long br0 = (long)blockIdx.x * 16;
-  for (int i = tid; i < 16 * 264; i += 512) {
-    const int p = i / 264, t = i - p * 264;
+  for (int i = tid; i < 16 * 268; i += 512) {
+    const int p = i / 268, t = i - p * 268;
     const long br = br0 + p;
     float v = 0.f;
     if (br < rowsBR && t < L) v = emb[((br / R) * L + t) * De + (br % R)];       // s == 1: representation r reads embedding column r
@@ -170,16 +170,33 @@ __global__ __launch_bounds__(512) void disc_conv_pool_fwd_mfma_kernel(const floa
       const float b0 = (ok && lk < f) ? wk[(long)ch * f + lk] : 0.f;
       const float b1 = (ok && 4 + lk < f) ? wk[(long)ch * f + 4 + lk] : 0.f;
       const float bias = ok ? bk[ch] : 0.f;
-      float best[4] = {-1.f, -1.f, -1.f, -1.f};
+      // relu then max over time with the first index on ties (discriminator.py:42,45) = a running maximum that starts at (0, t = 0)
+      // and moves on strictly greater pre-activations only: one compare and two selects per element.  The epilogue is VALU work
+      // of the size of the MFMAs it follows, so four time steps go together (independent accumulators under the previous ones'
+      // selects; steps past T read the zero padding and are skipped).
+      float best[4] = {0.f, 0.f, 0.f, 0.f};
       int bt[4] = {0, 0, 0, 0};
-      for (int t = 0; t < T; ++t) {
-        f32x4 acc = {bias, bias, bias, bias};
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[li][t + lk], b0, acc, 0, 0, 0);
-        if (f > 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[li][t + 4 + lk], b1, acc, 0, 0, 0);
+      for (int t0 = 0; t0 < T; t0 += 4) {
+        f32x4 acc[4];
+        float xa[4], xb[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = fmaxf(acc[r], 0.f);                    // relu then max over time, first index on ties
-          if (v > best[r]) { best[r] = v; bt[r] = t; }
+        for (int u = 0; u < 4; ++u) { xa[u] = xs[li][t0 + u + lk]; xb[u] = xs[li][t0 + u + 4 + lk]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[u] = (f32x4){bias, bias, bias, bias};
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u], b0, acc[u], 0, 0, 0);
+        }
+        if (f > 4) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[u], b1, acc[u], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (t0 + u < T) {                                      // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (acc[u][r] > best[r]) { best[r] = acc[u][r]; bt[r] = t0 + u; }
+          }
         }
       }
       // accumulator row 4 lk + r = pair, column li = filter
