@@ -302,19 +302,29 @@ class Encoder(nn.Module):
                                     self.linear.weight, self.linear.bias, self.bn.weight, self.bn.bias,
                                     self.bn.running_mean, self.bn.running_var)
 
-    def forward_with_map(self, images):
-        """(features [B,E] as forward(), feature map [B, P, C] = the trunk's last activation, detached) for the attention decoder."""
+    def forward_with_map(self, images, next_images=None):
+        """(features [B,E] as forward(), feature map [B, P, C] = the trunk's last activation, detached) for the attention decoder.
+        ``next_images``: as in forward() -- the look-ahead pass also keeps a copy of its feature map."""
         with torch.no_grad():
             main = torch.cuda.current_stream(images.device)
+            start = main.record_event()
             pre, self._pre = getattr(self, "_pre", None), None
+            fmap = None
             if pre is not None:
-                main.wait_event(pre[3])             # an unused look-ahead pass on the shared plan buffers
-            busy = getattr(self, "_busy", None)
-            if busy is not None:
-                main.wait_event(busy)
-            feats = self.trunk_features(images, self.training).clone()      # always a pass here: the map is the plan's live buffer
-            fmap = self.resnet._plan.last_map(images.shape[0], images.shape[2]).clone()
-            self._busy = main.record_event()
+                main.wait_event(pre[3])             # the look-ahead pass (used or not: it shares the plan's buffers)
+                if pre[0] is images and pre[1] == bool(self.training) and pre[4] is not None:
+                    feats, fmap = pre[2], pre[4]
+                    feats.record_stream(main)
+                    fmap.record_stream(main)
+            if fmap is None:
+                busy = getattr(self, "_busy", None)
+                if busy is not None:
+                    main.wait_event(busy)
+                feats = self.trunk_features(images, self.training).clone()      # a pass here: the map is the plan's live buffer
+                fmap = self.resnet._plan.last_map(images.shape[0], images.shape[2]).clone()
+                self._busy = main.record_event()
+            if next_images is not None:
+                self.prefetch_trunk(next_images, self.training, start, want_map=True)
         feats = feats.reshape(feats.size(0), -1)
         out = _EncoderHeadFn.apply(_compute_dtype(self.args), self.training, self.bn.momentum, self.bn.eps, feats,
                                    self.linear.weight, self.linear.bias, self.bn.weight, self.bn.bias,
@@ -323,7 +333,7 @@ class Encoder(nn.Module):
 
     # ---- trunk look-ahead: the trunk is frozen (generator.py:21), so the pass for the NEXT batch depends on nothing the current
     # step updates; it runs on its own stream under the step's launch-bound phases and hands over a private copy of its output.
-    def prefetch_trunk(self, images, training: bool, after, mark=None) -> None:
+    def prefetch_trunk(self, images, training: bool, after, mark=None, want_map: bool = False) -> None:
         if getattr(self, "_s_pre", None) is None:
             self._s_pre = torch.cuda.Stream(device=images.device)
         s = self._s_pre
@@ -337,11 +347,12 @@ class Encoder(nn.Module):
             if mark is not None:
                 mark("trunk prefetch start [s_pre]", s)
             feats = self.trunk_features(images, training).clone()
+            fmap = self.resnet._plan.last_map(images.shape[0], images.shape[2]).clone() if want_map else None
             done = s.record_event()
             if mark is not None:
                 mark("trunk prefetch done [s_pre]", s)
         images.record_stream(s)
-        self._pre = (images, bool(training), feats, done)
+        self._pre = (images, bool(training), feats, done, fmap)
 
     def take_trunk(self, images, training: bool, stream):
         """Trunk features of ``images`` on ``stream``: the prefetched copy if this very tensor was announced, else a pass now."""

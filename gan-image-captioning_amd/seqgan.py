@@ -48,7 +48,7 @@ class SeqGANStep:
         return self._grads
 
     def __call__(self, images, captions, max_caption_len: int, train: bool = True, u_sample: Optional[torch.Tensor] = None,
-                 u_mc: Optional[torch.Tensor] = None, keep_masks=None, opt_step: bool = True) -> dict:
+                 u_mc: Optional[torch.Tensor] = None, keep_masks=None, opt_step: bool = True, next_images=None) -> dict:
         """One step.  ``u_sample`` [L,B,V] / ``u_mc`` [L,(L-1)*N*B,V] / ``keep_masks`` (2 x [B*R,F]: real, fake) make it deterministic
         (parity runs); otherwise noise is drawn on the device.  Returns device tensors: losses [g_loss, d_loss], ids (Y), rewards."""
         gen, disc = self.gen, self.disc
@@ -61,7 +61,11 @@ class SeqGANStep:
         dec, den = self.dec, self.den
         R = den.R
         if self.cgan:
-            feats = gen.encoder.forward_fused(images, train, trunk_feats=gen.encoder.take_trunk(images, train, torch.cuda.current_stream(dev)))
+            main = torch.cuda.current_stream(dev)
+            start = main.record_event()
+            feats = gen.encoder.forward_fused(images, train, trunk_feats=gen.encoder.take_trunk(images, train, main))
+            if next_images is not None:          # the frozen trunk's pass for the next batch runs under this step (generator.Encoder)
+                gen.encoder.prefetch_trunk(next_images, train, start)
         else:
             ones = torch.ones(B, device=dev, dtype=torch.int64)
             feats = engine.embedding_fwd(gparams[0], ones)

@@ -136,7 +136,7 @@ class GANInstructor:
     # ------------------------------------------------------------------ shared pieces
     def _features(self, images, batch, next_images=None):
         if self.attention:
-            return self.gen.encoder.forward_with_map(images)               # (features, feature map)
+            return self.gen.encoder.forward_with_map(images, next_images=next_images)      # (features, feature map)
         if self.cgan:
             return self.gen.encoder(images, next_images=next_images)       # training.py:66,145
         ones = torch.ones(batch, dtype=torch.long, device=self.args.device)
@@ -218,16 +218,16 @@ class GANInstructor:
         ``next_images`` (optional): the next batch's images on the device, for the trunk prefetch of the fused step."""
         impl = getattr(self.args, "step_impl", "fused")
         if getattr(self.args, "adv_mode", "relgan") == "seqgan":
-            return self.seqgan(images, captions, max_caption_len, train)["losses"]
+            return self.seqgan(images, captions, max_caption_len, train, next_images=next_images)["losses"]
         if impl == "fused":
             return self.fused(images, captions, max_caption_len, train, noise_u, keep_masks, next_images=next_images)["losses"]
-        return self._adv_step_autograd(images, captions, max_caption_len, train, noise_u, keep_masks)
+        return self._adv_step_autograd(images, captions, max_caption_len, train, noise_u, keep_masks, next_images=next_images)
 
-    def _adv_step_autograd(self, images, captions, max_caption_len, train, noise_u=None, keep_masks=None):
+    def _adv_step_autograd(self, images, captions, max_caption_len, train, noise_u=None, keep_masks=None, next_images=None):
         """The reference's flow through the module API + autograd, with the fixed order."""
         km = keep_masks if keep_masks is not None else (None, None, None)
         with (torch.enable_grad() if train else torch.no_grad()):
-            features = self._features(images, captions.shape[0])
+            features = self._features(images, captions.shape[0], next_images if self.cgan else None)
             if self.attention:
                 gen_captions, _ids = self.gen.decoder.sample(features[0], fmap=features[1], max_caption_len=max_caption_len, noise_u=noise_u)
             else:
