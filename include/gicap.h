@@ -110,7 +110,8 @@ typedef struct gic_decoder_state {
   float* logits;                         /* scratch [B, V] */
   float* gpre;                           /* scratch [B, 4H] */
   float* part;                           /* scratch of the fused step kernels: [2][L][B][ceil(V/64)] per-tile softmax partials (max, sum of
-                                            exp) + [L][B] 64-bit argmax keys; size from gic_decoder_state_bytes, 8-byte aligned.
+                                            exp) + [L][B] 64-bit argmax keys + two 32-bit words of the opt-in persistent roll-out kernel (barrier counter, error
+                                            flag); size from gic_decoder_state_bytes, 8-byte aligned.
                                             NULL selects the unfused launches. */
 } gic_decoder_state;
 
