@@ -85,6 +85,55 @@ def test_conv2d_matches_torch(dev, case, dtype):
     close(stats[Co:], s2, rtol=1e-3, what="bn sumsq")
 
 
+@pytest.mark.parametrize("case", [(3, 64, 10, 14, 64), (2, 128, 5, 33, 72), (7, 64, 3, 3, 128), (1, 320, 21, 8, 64), (9, 64, 57, 6, 64),
+                                  (2, 64, 1, 40, 64), (5, 192, 13, 13, 200)])
+def test_patch_resident_conv3x3_on_odd_shapes(dev, case):
+    """conv3x3.hip away from the ResNet shapes: non-square maps, widths around the 64-pixel piece stride, single rows, tiles that
+    cross many small images, a ragged output-channel tile, five 64-channel chunks -- against torch (float64) on bf16-rounded operands,
+    with and without BatchNorm + ReLU on load (the latter against the normalised tensor convolved the same way)."""
+    from gan_image_captioning_amd import engine
+    L = _lib()
+    lib = L.load()
+    N, Ci, H, W, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = (torch.randn(N, Ci, H, W, generator=g)).bfloat16().float()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.1).bfloat16().float()
+    want = F.conv2d(x.double(), w.double(), None, 1, 1)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).bfloat16()
+    wp = w.permute(0, 2, 3, 1).contiguous().to(dev).bfloat16()
+    y = torch.empty(N, H, W, Co, device=dev, dtype=torch.bfloat16)
+    stats = torch.zeros(4, 2 * Co, device=dev)
+    s = engine.stream_ptr()
+    L.check(lib.gic_conv2d(xh.data_ptr(), wp.data_ptr(), y.data_ptr(), stats.data_ptr(), 4, 1, N, H, W, Ci, Co, 3, 3, 1, 1, s), "conv2d")
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2).double()
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err < 8e-3 * max(1.0, (Ci * 9 / 64) ** 0.5), f"{case}: rel max err {err}"
+    close(stats.sum(0)[:Co].cpu(), want.sum((0, 2, 3)), rtol=2e-3, atol_scale=1e-3 * (N * H * W) ** 0.5, what="bn sum")
+    # BatchNorm + ReLU on load: statistics of x itself, random affine
+    rows = N * H * W
+    xf = xh.float().reshape(rows, Ci)
+    in_stats = torch.zeros(3, 2 * Ci, device=dev)
+    in_stats[0, :Ci] = xf.sum(0)
+    in_stats[2, Ci:] = (xf * xf).sum(0)
+    gamma = (torch.rand(Ci, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(Ci, generator=g) * 0.2).to(dev)
+    mean = xf.mean(0)
+    var = ((xf * xf).mean(0) - mean * mean).clamp_min(0)
+    sc = gamma * torch.rsqrt(var + 1e-5)
+    z = torch.relu(xf * sc + (beta - mean * sc)).bfloat16().float().reshape(N, H, W, Ci).permute(0, 3, 1, 2).cpu()
+    want2 = F.conv2d(z.double(), w.double(), None, 1, 1)
+    y2 = torch.empty_like(y)
+    st2 = torch.zeros_like(stats)
+    status = lib.gic_conv2d_bn_in(xh.data_ptr(), in_stats.data_ptr(), 3, gamma.data_ptr(), beta.data_ptr(), float(rows), wp.data_ptr(),
+                                  y2.data_ptr(), st2.data_ptr(), 4, 1, N, H, W, Ci, Co, 3, 3, 1, 1, s)
+    torch.cuda.synchronize()
+    L.check(status, "conv2d_bn_in")
+    got2 = y2.float().cpu().permute(0, 3, 1, 2).double()
+    err2 = float((got2 - want2).abs().max() / want2.abs().max())
+    assert err2 < 1.2e-2 * max(1.0, (Ci * 9 / 64) ** 0.5), f"{case} with bn on load: rel max err {err2}"
+
+
 def test_trunk_forward_bf16_at_bench_resolution(dev, monkeypatch):
     """ResNet-50 at 224x224, 16 images: the grids of the benchmark's layers (1-, 2- and 4-stage rings, ring-less shallow-K launches,
     BatchNorm on load in every conv3, per-layer replica counts) against the fp32 CPU restatement; graph replay equals eager launches;
