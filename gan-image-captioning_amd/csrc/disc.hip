@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void disc_conv_pool_fwd_kernel(const float* __
       }
     }
     pooled[(long)br * cm.Fp + col] = from_f32<TA>(best);
-    argmax[(long)br * cm.Fp + col] = (uint8_t)bt;
+    if (argmax) argmax[(long)br * cm.Fp + col] = (uint8_t)bt;
   }
 }
 
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512) void disc_conv_pool_fwd_mfma_kernel(const floa
           const long br = br0 + 4 * lk + r;
           if (br < rowsBR) {
             pooled[br * cm.Fp + col] = from_f32<TA>(best[r]);
-            argmax[br * cm.Fp + col] = (uint8_t)bt[r];
+            if (argmax) argmax[br * cm.Fp + col] = (uint8_t)bt[r];
           }
         }
       }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) void disc_conv_pool_fwd_mfma_kernel(const floa
   for (int i = tid; i < 16 * (cm.Fp - cm.F); i += 512) {
     const int p = i / (cm.Fp - cm.F), c = cm.F + i % (cm.Fp - cm.F);
     const long br = br0 + p;
-    if (br < rowsBR) { pooled[br * cm.Fp + c] = from_f32<TA>(0.f); argmax[br * cm.Fp + c] = 0; }
+    if (br < rowsBR) { pooled[br * cm.Fp + c] = from_f32<TA>(0.f); if (argmax) argmax[br * cm.Fp + c] = 0; }
   }
 }
 
@@ -743,7 +743,8 @@ int gic_disc_fwd(const gic_disc_dims* dims, const gic_disc_params* P, const gic_
   GIC_CHECK_ARG(P && S && st && logits, "disc_fwd: null argument");
   GIC_CHECK_ARG((inp_soft != nullptr) != (inp_ids != nullptr), "disc_fwd: pass exactly one of inp_soft / inp_ids");
   GIC_CHECK_ARG(!inp_soft || ld_inp >= c.V, "disc_fwd: ld_inp < V");
-  GIC_CHECK_ARG(st->emb && st->pooled && st->argmax && st->hpre && st->ydrop && st->feat && (!train || st->keep), "disc_fwd: null state buffer");
+  // forward only (eval mode, no backward to follow): state->argmax and state->hpre may be NULL and are then not written
+  GIC_CHECK_ARG(st->emb && st->pooled && st->ydrop && st->feat && (!train || (st->keep && st->argmax && st->hpre)), "disc_fwd: null state buffer");
   GIC_CHECK_ARG(P->emb && P->hw_b && P->f2o_b && P->o2l_w && P->o2l_b && S->emb && S->hw_w && S->f2o_w, "disc_fwd: null parameter");
   if (c.dt == DT_F32)
     return disc_fwd_t<float>(c, P, S, st, inp_soft, ld_inp, inp_ids, train, keep_mask, seed, logits, (hipStream_t)stream);

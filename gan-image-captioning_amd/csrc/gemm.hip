@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
           const float x = to_f32<TI>(((const TI*)d.X)[(long)m * d.ldx + n]);
           const float sg = 1.f / (1.f + expf(-v));
           const float y = sg * fmaxf(v, 0.f) + (1.f - sg) * x;
-          d.Hpre[(long)m * d.ldh + n] = v;
+          if (d.Hpre) d.Hpre[(long)m * d.ldh + n] = v;          // (null: forward only, nothing saved for a backward pass)
           float keep = keep4[r];
           if (d.mask) keep = (float)d.mask[(long)m * d.ldmask + n];
           if (d.mask_out) d.mask_out[(long)m * d.ldmask_out + n] = (uint8_t)keep;
@@ -909,8 +909,10 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
             kb |= (unsigned long long)(live ? (unsigned)k : 0u) << (8 * e);
             yv[e] = (bf16_t)(live ? y * k * d.keep_scale : 0.f);
           }
-          *(float4*)(d.Hpre + (long)m * d.ldh + n0) = h0;
-          *(float4*)(d.Hpre + (long)m * d.ldh + n0 + 4) = h1;
+          if (d.Hpre) {
+            *(float4*)(d.Hpre + (long)m * d.ldh + n0) = h0;
+            *(float4*)(d.Hpre + (long)m * d.ldh + n0 + 4) = h1;
+          }
           if (d.mask_out) *(unsigned long long*)(d.mask_out + (long)m * d.ldmask_out + n0) = kb;
           *(bf16x8*)((bf16_t*)C + (long)m * d.ldc + n0) = yv;
         }
@@ -943,7 +945,7 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
           const float x = to_f32<bf16_t>(((const bf16_t*)d.X)[(long)m * d.ldx + n]);
           const float sg = 1.f / (1.f + expf(-v));
           const float y = sg * fmaxf(v, 0.f) + (1.f - sg) * x;
-          d.Hpre[(long)m * d.ldh + n] = v;
+          if (d.Hpre) d.Hpre[(long)m * d.ldh + n] = v;          // (null: forward only, nothing saved for a backward pass)
           float keep = keep4[r];
           if (d.mask) keep = (float)d.mask[(long)m * d.ldmask + n];
           if (d.mask_out) d.mask_out[(long)m * d.ldmask_out + n] = (uint8_t)keep;
@@ -1241,7 +1243,7 @@ int gemm(const GemmDesc& d0, hipStream_t stream) {
   GIC_CHECK_ARG(d.A && d.B && d.C, "gemm: null operand");
   GIC_CHECK_ARG(d.M >= 0 && d.N >= 0 && d.K >= 0, "gemm: negative dim");
   if (d.M == 0 || d.N == 0) return GIC_OK;
-  if (d.epi == EPI_HIGHWAY) GIC_CHECK_ARG(d.X && d.Hpre, "gemm: highway epilogue needs X and Hpre");
+  if (d.epi == EPI_HIGHWAY) GIC_CHECK_ARG(d.X, "gemm: highway epilogue needs X");      // Hpre may be null (forward only)
   const int sz = dtype_size(d.in_dtype);
   const int ve = 16 / sz;
   bool vec = aligned16(d.A) && aligned16(d.B) && (d.lda % ve == 0) && (d.ldb % ve == 0);

@@ -501,9 +501,17 @@ class DiscEngine:
         s.hw_w_t = ptr(sh["hw_w_t"])
         return s
 
-    def alloc_state(self, B: int, Lc: int, dev):
+    def alloc_state(self, B: int, Lc: int, dev, forward_only: bool = False):
+        """``forward_only``: an eval-mode forward that no backward follows (reward evaluation): no argmax / pre-activation / keep
+        buffers (gic_disc_fwd then writes none), and only the pad columns of ``ydrop`` are zeroed."""
         f32, u8 = torch.float32, torch.uint8
         MR = B * self.R
+        if forward_only:
+            ydrop = torch.empty(MR, self.Fp, device=dev, dtype=self.act)
+            if self.Fp > self.F:
+                ydrop[:, self.F:].zero_()
+            return {"emb": torch.empty(B * Lc, self.De, device=dev, dtype=f32), "pooled": torch.empty(MR, self.Fp, device=dev, dtype=self.act),
+                    "argmax": None, "hpre": None, "keep": None, "ydrop": ydrop, "feat": torch.empty(MR, self.OUT, device=dev, dtype=f32)}
         return {
             "emb": torch.empty(B * Lc, self.De, device=dev, dtype=f32),
             "pooled": torch.empty(MR, self.Fp, device=dev, dtype=self.act),
@@ -517,7 +525,7 @@ class DiscEngine:
     def _state_struct(self, st) -> L.DiscState:
         s = L.DiscState()
         for k in ("emb", "pooled", "argmax", "hpre", "keep", "ydrop", "feat"):
-            setattr(s, k, ptr(st[k]))
+            setattr(s, k, ptr(st.get(k)))
         return s
 
     def alloc_bwd_ws(self, B: int, Lc: int, dev):
@@ -546,7 +554,10 @@ class DiscEngine:
         return inp
 
     def fwd(self, params, inp_soft: Optional[torch.Tensor], inp_ids: Optional[torch.Tensor], train: bool,
-            keep_mask: Optional[torch.Tensor] = None, seed: int = 0, state=None, logits=None):
+            keep_mask: Optional[torch.Tensor] = None, seed: int = 0, state=None, logits=None, forward_only: bool = False):
+        """``forward_only`` (eval mode only): nothing is saved for a backward pass (see alloc_state)."""
+        if forward_only and train:
+            raise ValueError("forward_only is an eval-mode option: the train-mode forward saves its dropout mask for the backward")
         self.check_params(params)
         src = inp_soft if inp_soft is not None else inp_ids
         require_gpu(src, keep_mask)
@@ -561,7 +572,7 @@ class DiscEngine:
                 raise ValueError(f"keep_mask must be [B*R={B * self.R}, F={self.F}]")
             keep_mask = keep_mask.to(torch.uint8).contiguous()
         self.prepare(params)
-        st = state if state is not None else self.alloc_state(B, Lc, dev)
+        st = state if state is not None else self.alloc_state(B, Lc, dev, forward_only=forward_only)
         logits = logits if logits is not None else torch.empty(B * self.R, device=dev, dtype=torch.float32)
         d = self.dims(B, Lc)
         L.check(L.load().gic_disc_fwd(

@@ -87,8 +87,8 @@ class SeqGANStep:
                 resume = (st, B, [min(t, L - 1) * N * B for t in range(L)])
             _, mc_ids, _ = dec.sample_fwd(gparams, f_big, L, 1.0, noise_u=u_mc, seed=0 if u_mc is not None else SEEDS.next(),
                                           ids_only=True, force_ids=force, force_len=flen, resume=resume)
-            mc_logits, _ = den.fwd(dparams, None, mc_ids, False)
-        full_logits, _ = den.fwd(dparams, None, Y, False)
+            mc_logits, _ = den.fwd(dparams, None, mc_ids, False, forward_only=True)     # rewards: no backward follows
+        full_logits, _ = den.fwd(dparams, None, Y, False, forward_only=True)
         rewards = engine.rollout_rewards(mc_logits, full_logits, B, L, N, R)
         out = {"ids": Y, "rewards": rewards}
         # 4b. REINFORCE

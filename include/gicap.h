@@ -337,7 +337,8 @@ int gic_disc_prepare(const gic_disc_dims* dims, const gic_disc_params* params, c
 /* Exactly one of inp_soft (act [B*L, V], row stride ld_inp, rows in (b,l) order) and inp_ids (int64 [B,L];
  * the one-hot of training.py:158 evaluated as a gather) is non-NULL.
  * train != 0: dropout(dims->drop_p) with keep_mask (uint8 0/1 [B*R,F], row stride F) or, if NULL, Philox(seed).
- * logits: f32 [B*R]. */
+ * train == 0 with state->argmax == NULL and / or state->hpre == NULL: a forward that no backward follows (reward evaluation of
+ * the SeqGAN-style step): those buffers are not written.  logits: f32 [B*R]. */
 int gic_disc_fwd(const gic_disc_dims* dims, const gic_disc_params* params, const gic_disc_shadow* shadow,
                  const gic_disc_state* state, const void* inp_soft, int64_t ld_inp, const int64_t* inp_ids,
                  int train, const uint8_t* keep_mask, uint64_t seed, float* logits, void* stream);
