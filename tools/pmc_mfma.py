@@ -12,8 +12,9 @@ acc = {}
 with open(sys.argv[1]) as fh:
     for row in csv.DictReader(fh):
         name = row["Kernel_Name"]
-        # the trunk's convolution kernels: tile8 (implicit GEMM) and the patch-resident 3x3 kernel
-        key = "conv" if (("tile8_kernel" in name and "Lb1E" in name) or "conv3x3_patch_kernel" in name) else ("bn_act" if "bn_act_kernel" in name else None)
+        # the trunk's convolution kernels: tile8 (implicit GEMM), the patch-resident 3x3, the streaming and the panel-resident 1x1 kernels
+        conv = ("tile8_kernel" in name and "Lb1E" in name) or any(k in name for k in ("conv3x3_patch_kernel", "conv1x1_stream_kernel", "conv1x1_panel_kernel"))
+        key = "conv" if conv else ("bn_act" if "bn_act_kernel" in name else None)
         if key is None:
             continue
         d = acc.setdefault(key, {})
