@@ -143,4 +143,18 @@ struct Philox {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Dynamic LDS beyond 64 KB must be granted per kernel (hipFuncAttributeMaxDynamicSharedMemorySize).  `granted` = what the kernel
+// already has: one static per kernel instantiation at the call site, so the attribute is set once (outside any stream capture: every
+// plan runs its first pass eagerly).  false: the runtime refused (the caller falls back or reports).
+template <typename Kf>
+static inline bool grant_lds(Kf kernel, size_t bytes, size_t& granted) {
+  if (bytes <= granted) return true;
+  if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  granted = bytes;
+  return true;
+}
+
 }  // namespace gic

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "conv1x1_panel.h"
+#include "bn_fold.h"
 
 namespace gic {
 namespace {
@@ -17,25 +18,6 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// Sum / sum of squares of channel c over the replicas of a BatchNorm statistics arena [nrep][2][C] (eight pairs of loads in flight)
-__device__ __forceinline__ void fold_replicas(const float* stats, int nrep, int C, int c, float& s1, float& s2) {
-  s1 = s2 = 0.f;
-  for (int r0 = 0; r0 < nrep; r0 += 8) {
-    float a[8], q[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const long rr = min(r0 + r, nrep - 1);
-      a[r] = stats[rr * 2 * C + c];
-      q[r] = stats[rr * 2 * C + C + c];
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float wgt = r0 + r < nrep ? 1.f : 0.f;
-      s1 += wgt * a[r]; s2 += wgt * q[r];
-    }
-  }
-}
 
 // everything the kernel reads from its arguments, compact (one batch of scalar loads at the top)
 struct PanelDesc {
@@ -209,17 +191,6 @@ __global__ __launch_bounds__(512) void conv1x1_panel_kernel(const PanelDesc d) {
     st ^= 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (the zero-fill DMA of the tile past the group)
-}
-
-template <typename Kf>
-bool grant_lds(Kf kernel, size_t bytes, size_t& granted) {
-  if (bytes <= granted) return true;
-  if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-    (void)hipGetLastError();
-    return false;
-  }
-  granted = bytes;
-  return true;
 }
 
 template <int KT, bool ABN>

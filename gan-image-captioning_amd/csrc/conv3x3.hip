@@ -25,6 +25,7 @@
 #include <tuple>
 
 #include "conv3x3.h"
+#include "bn_fold.h"
 
 namespace gic {
 #ifdef GIC_STAMPS
@@ -41,25 +42,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int N> __device__ __forceinline__ void wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// Sum / sum of squares of channel c over the replicas of a BatchNorm statistics arena [nrep][2][C] (eight pairs of loads in flight)
-__device__ __forceinline__ void fold_replicas(const float* stats, int nrep, int C, int c, float& s1, float& s2) {
-  s1 = s2 = 0.f;
-  for (int r0 = 0; r0 < nrep; r0 += 8) {
-    float a[8], q[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const long rr = min(r0 + r, nrep - 1);
-      a[r] = stats[rr * 2 * C + c];
-      q[r] = stats[rr * 2 * C + C + c];
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float wgt = r0 + r < nrep ? 1.f : 0.f;
-      s1 += wgt * a[r]; s2 += wgt * q[r];
-    }
-  }
-}
 
 // Which of the 16 pixels of a fragment's segment MFMA row x holds.  ds_read_b128 serves a wave in groups of lanes {0-3, 12-15,
 // 20-27}, ...: rows 0-3 and 12-15 of one 16-byte channel chunk together with rows 4-11 of the NEXT chunk.  With pixel p's chunk c
@@ -371,17 +353,6 @@ int max_patch_pixels(int Nimg, int H, int W, bool per_image) {
   }
   cache[key] = best;
   return best;
-}
-
-template <typename K>
-bool grant_lds(K kernel, size_t bytes, size_t& granted) {
-  if (bytes <= granted) return true;
-  if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-    (void)hipGetLastError();
-    return false;
-  }
-  granted = bytes;
-  return true;
 }
 
 template <int BN, int P, bool MULTI, bool ABN>

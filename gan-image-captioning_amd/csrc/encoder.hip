@@ -14,6 +14,7 @@
 //   bn1d_fwd / bwd    the head's BatchNorm1d(momentum=0.01) on [B, E]
 #include "../../include/gicap.h"
 #include "kernels.h"
+#include "bn_fold.h"
 
 namespace gic {
 namespace {
@@ -68,24 +69,9 @@ struct BnSrc {            // y-side or residual-side BatchNorm inputs; stats == 
 __device__ __forceinline__ void bn_coeffs(const BnSrc& b, int c, int C, float inv_count, float& scale, float& shift) {
   float mean, var;
   if (b.stats) {
-    // the replicas' loads are independent: eight pairs in flight per round trip (a load / add loop waits for each replica in turn;
-    // replicas past nrep re-read the last one with weight 0)
-    const float g = b.gamma[c], bt = b.beta[c];
-    float s1 = 0.f, s2 = 0.f;
-    for (int r0 = 0; r0 < b.nrep; r0 += 8) {
-      float a[8], q[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const long rr = min(r0 + r, b.nrep - 1);
-        a[r] = b.stats[rr * 2 * C + c];
-        q[r] = b.stats[rr * 2 * C + C + c];
-      }
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const float wgt = r0 + r < b.nrep ? 1.f : 0.f;
-        s1 += wgt * a[r]; s2 += wgt * q[r];
-      }
-    }
+    const float g = b.gamma[c], bt = b.beta[c];              // in flight together with the replicas (bn_fold.h)
+    float s1, s2;
+    fold_replicas(b.stats, b.nrep, C, c, s1, s2);
     mean = s1 * inv_count;
     var = fmaxf(s2 * inv_count - mean * mean, 0.f);
     scale = g * rsqrtf(var + kBnEps);

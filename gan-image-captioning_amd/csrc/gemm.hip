@@ -15,6 +15,7 @@
 #include "conv3x3.h"
 #include "conv1x1_stream.h"
 #include "conv1x1_panel.h"
+#include "bn_fold.h"
 
 #include <stdlib.h>
 
@@ -42,26 +43,6 @@ namespace {
 #define STAMP(i) do {} while (0)
 #define DBG 0
 #endif
-
-// Sum / sum of squares of channel c over the replicas of a BatchNorm statistics arena [nrep][2][C]: eight independent pairs of loads
-// in flight per round trip (a load / add loop waits for each replica in turn); replicas past nrep re-read the last one with weight 0.
-__device__ __forceinline__ void fold_replicas(const float* stats, int nrep, int C, int c, float& s1, float& s2) {
-  s1 = s2 = 0.f;
-  for (int r0 = 0; r0 < nrep; r0 += 8) {
-    float a[8], q[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const long rr = min(r0 + r, nrep - 1);
-      a[r] = stats[rr * 2 * C + c];
-      q[r] = stats[rr * 2 * C + C + c];
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float wgt = r0 + r < nrep ? 1.f : 0.f;
-      s1 += wgt * a[r]; s2 += wgt * q[r];
-    }
-  }
-}
 
 template <typename T> struct GlobalPtr { typedef const __attribute__((address_space(1))) T* type; };
 
