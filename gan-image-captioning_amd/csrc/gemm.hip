@@ -15,6 +15,7 @@
 #include "conv3x3.h"
 #include "conv1x1_stream.h"
 #include "conv1x1_panel.h"
+#include "conv_stem.h"
 #include "bn_fold.h"
 
 #include <stdlib.h>
@@ -1179,6 +1180,8 @@ int pick_conv(const GemmDesc& d, hipStream_t stream) {
   if constexpr (sizeof(TI) == 2 && sizeof(TO) == 2 && EPI == EPI_BNSTATS) {
     // 3x3 / stride 1: the input patch stays in LDS for all nine taps (conv3x3.hip).  BatchNorm on load of any other window than
     // 1x1 exists there only (tile8 would re-normalise the tile once per tap: slower than the separate pass it replaces).
+    // the stem (7 x 8 window over the zero-bordered NHWC4 image): input rows rolling through an LDS ring (conv_stem.hip)
+    if (try_conv_stem(d, stream)) { GIC_CHECK_LAUNCH("conv stem"); return GIC_OK; }
     if (try_conv3x3_patch(d, stream)) { GIC_CHECK_LAUNCH("conv3x3 patch"); return GIC_OK; }
     // shallow 1x1 layers over many rows: persistent workgroups, resident weights, A tiles streamed across row tiles (conv1x1_stream.hip)
     if (try_conv1x1_stream(d, stream)) { GIC_CHECK_LAUNCH("conv1x1 stream"); return GIC_OK; }

@@ -134,6 +134,34 @@ def test_patch_resident_conv3x3_on_odd_shapes(dev, case):
     assert err2 < 1.2e-2 * max(1.0, (Ci * 9 / 64) ** 0.5), f"{case} with bn on load: rel max err {err2}"
 
 
+@pytest.mark.parametrize("case", [(3, 70), (2, 230), (5, 38), (70, 134)])
+def test_streaming_stem_conv_matches_torch(dev, case):
+    """conv_stem.hip: window 7 x 8 over a pre-padded NHWC4 bf16 image, stride 2, 64 channels -- against torch (float64) on the same
+    bf16-rounded operands (all 8 x 4 window entries random: the kernel does not rely on the zero tap column / channel), output and
+    BatchNorm sums; image counts that give one and several row ranges per image, and a last range that is short."""
+    from gan_image_captioning_amd import engine
+    L = _lib()
+    lib = L.load()
+    N, S = case
+    g = torch.Generator().manual_seed(N * 1000 + S)
+    x = torch.randn(N, 4, S, S, generator=g).bfloat16().float()
+    w = (torch.randn(64, 4, 7, 8, generator=g) * 0.1).bfloat16().float()
+    want = F.conv2d(x.double(), w.double(), None, 2, 0)
+    Ho, Wo = want.shape[2], want.shape[3]
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).bfloat16()
+    wp = w.permute(0, 2, 3, 1).contiguous().to(dev).bfloat16()                       # [64, 7, 8, 4]
+    y = torch.empty(N, Ho, Wo, 64, device=dev, dtype=torch.bfloat16)
+    stats = torch.zeros(8, 128, device=dev)
+    L.check(lib.gic_conv2d(xh.data_ptr(), wp.data_ptr(), y.data_ptr(), stats.data_ptr(), 8, 1, N, S, S, 4, 64, 7, 8, 2, 0, engine.stream_ptr()), "conv2d")
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2).double()
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err < 1.5e-2, f"{case}: rel max err {err}"
+    rows = N * Ho * Wo
+    close(stats.sum(0)[:64].cpu(), want.sum((0, 2, 3)), rtol=2e-3, atol_scale=1e-3 * rows ** 0.5, what="bn sum")
+    close(stats.sum(0)[64:].cpu(), (want ** 2).sum((0, 2, 3)), rtol=2e-3, what="bn sumsq")
+
+
 def test_trunk_forward_bf16_at_bench_resolution(dev, monkeypatch):
     """ResNet-50 at 224x224, 16 images: the grids of the benchmark's layers (1-, 2- and 4-stage rings, ring-less shallow-K launches,
     BatchNorm on load in every conv3, per-layer replica counts) against the fp32 CPU restatement; graph replay equals eager launches;
