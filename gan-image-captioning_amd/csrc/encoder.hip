@@ -21,22 +21,42 @@ namespace {
 
 constexpr float kBnEps = 1e-5f;
 
-// ---- NCHW f32 [N,3,S,S] -> [N, S+2*pad, Wp, 4] act, zero border and zero 4th channel
-template <typename TA>
-__global__ void pack_image_kernel(const float* __restrict__ img, TA* __restrict__ out, int N, int S, int pad, int Hp, int Wp) {
-  const long total = (long)N * Hp * Wp;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int wp = (int)(i % Wp);
-    const long t = i / Wp;
-    const int hp = (int)(t % Hp), n = (int)(t / Hp);
-    const int h = hp - pad, w = wp - pad;
-    float v[3] = {0.f, 0.f, 0.f};
-    if (h >= 0 && h < S && w >= 0 && w < S) {
+// ---- NCHW f32 [N,3,S,S] -> [N, S+2*pad, Wp, 4] act, zero border and zero 4th channel.  A thread packs PX adjacent pixels (one 16-byte
+// store in bf16): unconditional loads from clamped coordinates (border pixels are zeroed by a select after the loads), 32-bit index math.
+template <typename TA, int PX>
+__global__ __launch_bounds__(256) void pack_image_kernel(const float* __restrict__ img, TA* __restrict__ out, int N, int S, int pad, int Hp, int Wp) {
+  const int groups = Wp / PX;                                        // pixel groups per row (launch code: Wp % PX == 0)
+  const int total = N * Hp * groups;                                 // < 2^31 (launch code)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int gq = i % groups, t = i / groups;
+    const int hp = t % Hp, n = t / Hp;
+    const int h = hp - pad;
+    const bool hok = h >= 0 && h < S;
+    const int hc = min(max(h, 0), S - 1);
+    float v[PX][3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) v[c] = img[(((long)n * 3 + c) * S + h) * S + w];
+    for (int q = 0; q < PX; ++q) {
+      const int w = gq * PX + q - pad;
+      const int wc = min(max(w, 0), S - 1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[q][c] = img[(((long)n * 3 + c) * S + hc) * S + wc];
     }
-    TA* o = out + i * 4;
-    o[0] = from_f32<TA>(v[0]); o[1] = from_f32<TA>(v[1]); o[2] = from_f32<TA>(v[2]); o[3] = from_f32<TA>(0.f);
+    TA o[PX * 4];
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+      const int w = gq * PX + q - pad;
+      const bool ok = hok && w >= 0 && w < S;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[q * 4 + c] = from_f32<TA>(ok ? v[q][c] : 0.f);
+      o[q * 4 + 3] = from_f32<TA>(0.f);
+    }
+    TA* dst = out + (long)i * (PX * 4);
+    if constexpr (sizeof(TA) * PX * 4 == 16) *(uint4*)dst = *(const uint4*)o;
+    else if constexpr (sizeof(TA) * PX * 4 == 8) *(uint2*)dst = *(const uint2*)o;
+    else {
+#pragma unroll
+      for (int q = 0; q < PX; ++q) *(uint4*)(dst + q * 4) = *(const uint4*)(o + q * 4);      // f32: 16 bytes per pixel
+    }
   }
 }
 
@@ -146,40 +166,49 @@ __global__ __launch_bounds__(1024) void bn_act_kernel(const TA* __restrict__ y, 
 }
 
 // ---- stem: relu(bn(y)) then 3x3 stride-2 pad-1 max-pool.  y [N,H,W,C] -> out [N,Ho,Wo,C]
+// The launch's thread count is a multiple of the channel-group count (launch code), so a thread keeps its channels: coefficients in
+// registers; the nine window loads of an output are unconditional (a coordinate outside the image is clamped onto the window's own edge
+// pixel: a duplicate inside a maximum changes nothing) and all in flight before the first use -- loads inside `if (inside)` made the
+// wave wait for each tap in turn.
 template <typename TA>
-__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const TA* __restrict__ y, BnSrc by, float inv_count, TA* __restrict__ out,
-                                                               int N, int H, int W, int C, int Ho, int Wo) {
+__global__ __launch_bounds__(1024) void bn_relu_maxpool_kernel(const TA* __restrict__ y, BnSrc by, float inv_count, TA* __restrict__ out,
+                                                                int N, int H, int W, int C, int Ho, int Wo) {
   extern __shared__ __attribute__((aligned(16))) float coef[];      // [2][C]
   constexpr int VN = Vec16<TA>::N;
   stage_coeffs(coef, by, C, inv_count);
   __syncthreads();
   const int cv = C / VN;
-  const long total = (long)N * Ho * Wo * cv;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cv) * VN;
-    long t = i / cv;
-    const int wo = (int)(t % Wo); t /= Wo;
-    const int ho = (int)(t % Ho);
-    const int n = (int)(t / Ho);
-    float best[VN];
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = (int)(i0 % cv) * VN;
+  float sc[VN], sh[VN];
 #pragma unroll
-    for (int k = 0; k < VN; ++k) best[k] = 0.f;          // relu output is >= 0 and every window holds >= 1 pixel
+  for (int k = 0; k < VN; ++k) { sc[k] = coef[c0 + k]; sh[k] = coef[C + c0 + k]; }
+  const int pixels = N * Ho * Wo;                                    // < 2^31 (launch code)
+  const int step = (int)((long)gridDim.x * blockDim.x / cv);
+  for (int p = (int)(i0 / cv); p < pixels; p += step) {
+    const int wo = p % Wo, t = p / Wo;
+    const int ho = t % Ho, n = t / Ho;
+    TA pv[9][VN];
+#pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const int h = ho * 2 - 1 + r;
-      if (h < 0 || h >= H) continue;
-      for (int s = 0; s < 3; ++s) {
-        const int w = wo * 2 - 1 + s;
-        if (w < 0 || w >= W) continue;
-        TA pv[VN];
-        *(uint4*)pv = *(const uint4*)(y + (((long)n * H + h) * W + w) * C + c0);
+      const int h = min(max(ho * 2 - 1 + r, 0), H - 1);
 #pragma unroll
-        for (int k = 0; k < VN; ++k) best[k] = fmaxf(best[k], to_f32<TA>(pv[k]) * coef[c0 + k] + coef[C + c0 + k]);
+      for (int q = 0; q < 3; ++q) {
+        const int w = min(max(wo * 2 - 1 + q, 0), W - 1);
+        *(uint4*)pv[r * 3 + q] = *(const uint4*)(y + (((long)n * H + h) * W + w) * C + c0);
       }
     }
+    float best[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) best[k] = 0.f;          // relu output is >= 0
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int k = 0; k < VN; ++k) best[k] = fmaxf(best[k], to_f32<TA>(pv[j][k]) * sc[k] + sh[k]);
     TA ov[VN];
 #pragma unroll
     for (int k = 0; k < VN; ++k) ov[k] = from_f32<TA>(best[k]);
-    *(uint4*)(out + (((long)n * Ho + ho) * Wo + wo) * C + c0) = *(const uint4*)ov;
+    *(uint4*)(out + (long)p * C + c0) = *(const uint4*)ov;
   }
 }
 
@@ -326,10 +355,15 @@ int gic_pack_image(const float* nchw, void* out, int dtype, int N, int S, int pa
   GIC_CHECK_ARG(nchw && out && N > 0 && S > 0 && pad >= 0 && Wp >= S + 2 * pad, "pack_image: bad argument");
   const int Hp = S + 2 * pad;
   const long total = (long)N * Hp * Wp;
-  if (dtype == DT_F32)
-    hipLaunchKernelGGL((pack_image_kernel<float>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, nchw, (float*)out, N, S, pad, Hp, Wp);
-  else
-    hipLaunchKernelGGL((pack_image_kernel<bf16_t>), dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, nchw, (bf16_t*)out, N, S, pad, Hp, Wp);
+  GIC_CHECK_ARG(total < (1l << 31) && (((uintptr_t)out) & 15) == 0, "pack_image: too many pixels or an unaligned output");
+  const hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_F32) {
+    hipLaunchKernelGGL((pack_image_kernel<float, 1>), dim3(grid1d(total, 8192)), dim3(256), 0, st, nchw, (float*)out, N, S, pad, Hp, Wp);
+  } else if (Wp % 2 == 0) {
+    hipLaunchKernelGGL((pack_image_kernel<bf16_t, 2>), dim3(grid1d(total / 2, 8192)), dim3(256), 0, st, nchw, (bf16_t*)out, N, S, pad, Hp, Wp);
+  } else {
+    hipLaunchKernelGGL((pack_image_kernel<bf16_t, 1>), dim3(grid1d(total, 8192)), dim3(256), 0, st, nchw, (bf16_t*)out, N, S, pad, Hp, Wp);
+  }
   GIC_CHECK_LAUNCH("pack_image");
   return GIC_OK;
 }
@@ -441,13 +475,22 @@ int gic_bn_relu_maxpool(const void* y, const float* stats, const float* gamma, c
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const BnSrc by = make_src(stats, stats_nrep, gamma, beta, run_mean, run_var);
   const size_t lds = (size_t)2 * C * sizeof(float);
-  if (dtype == DT_F32) {
-    const long total = (long)N * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL((bn_relu_maxpool_kernel<float>), dim3(grid1d(total, 1024)), dim3(256), lds, (hipStream_t)stream, (const float*)y, by, 1.f / count, (float*)out, N, H, W, C, Ho, Wo);
-  } else {
-    const long total = (long)N * Ho * Wo * (C / 8);
-    hipLaunchKernelGGL((bn_relu_maxpool_kernel<bf16_t>), dim3(grid1d(total, 1024)), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)y, by, 1.f / count, (bf16_t*)out, N, H, W, C, Ho, Wo);
+  const int cv = C / (dtype == DT_F32 ? 4 : 8);
+  const long total = (long)N * Ho * Wo * cv;
+  GIC_CHECK_ARG((long)N * Ho * Wo < (1l << 31), "bn_relu_maxpool: too many output pixels");
+  // 1024-thread blocks (few prologues); grid * 1024 a multiple of the channel-group count: threads keep their channels
+  int grid = (int)((total + 1023) / 1024);
+  grid = grid < 1 ? 1 : (grid > 1024 ? 1024 : grid);
+  {
+    int step = cv, t = 1024;
+    while (t) { const int m = step % t; step = t; t = m; }       // gcd(cv, 1024)
+    const int mult = cv / step;
+    grid = (grid + mult - 1) / mult * mult;
   }
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL((bn_relu_maxpool_kernel<float>), dim3(grid), dim3(1024), lds, (hipStream_t)stream, (const float*)y, by, 1.f / count, (float*)out, N, H, W, C, Ho, Wo);
+  else
+    hipLaunchKernelGGL((bn_relu_maxpool_kernel<bf16_t>), dim3(grid), dim3(1024), lds, (hipStream_t)stream, (const bf16_t*)y, by, 1.f / count, (bf16_t*)out, N, H, W, C, Ho, Wo);
   GIC_CHECK_LAUNCH("bn_relu_maxpool");
   return GIC_OK;
 }
