@@ -270,6 +270,44 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const TA* __restrict__
   }
 }
 
+// ---- the same with the row held in registers: 16-byte loads of p and dp, all in flight at once, ONE pass over them (V % (16 / sizeof) == 0,
+// V <= 256 * NCH * (16 / sizeof)); the scalar kernel above reads both rows twice, two bytes per lane at a time.
+template <typename TA, int NCH>
+__global__ __launch_bounds__(256) void softmax_bwd_vec_kernel(const TA* __restrict__ p, const TA* __restrict__ dp,
+                                                               TA* __restrict__ dl, float temperature, int V) {
+  constexpr int VN = 16 / (int)sizeof(TA);
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const int nch = V / VN;
+  TA pv[NCH][VN], dv[NCH][VN];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    const long o = row * V + (long)(c < nch ? c : 0) * VN;           // chunks past the row re-read chunk 0 (not used)
+    *(uint4*)pv[i] = *(const uint4*)(p + o);
+    *(uint4*)dv[i] = *(const uint4*)(dp + o);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    if (threadIdx.x + 256 * i < nch) {
+#pragma unroll
+      for (int k = 0; k < VN; ++k) s += to_f32<TA>(pv[i][k]) * to_f32<TA>(dv[i][k]);
+    }
+  }
+  s = block_sum(s, red);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < nch) {
+      TA ov[VN];
+#pragma unroll
+      for (int k = 0; k < VN; ++k) ov[k] = from_f32<TA>(temperature * to_f32<TA>(pv[i][k]) * (to_f32<TA>(dv[i][k]) - s));
+      *(uint4*)(dl + row * V + (long)c * VN) = *(const uint4*)ov;
+    }
+  }
+}
+
 // Wcat = [w_ih | w_hh] in the compute dtype, bsum = b_ih + b_hh
 template <typename TA>
 __global__ void build_wcat_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
@@ -628,12 +666,25 @@ int decoder_output_bwd(int dt, int B, int L, int V, int H, const void* probs, co
   const long BL = (long)B * L;
   const void* dlog = pretrain ? d_out : (const void*)dlogits_ws;
   if (!pretrain) {
-    if (dt == DT_F32)
-      hipLaunchKernelGGL((softmax_bwd_kernel<float>), dim3((unsigned)BL), dim3(256), 0, stream, (const float*)probs, (const float*)d_out,
-                         (float*)dlogits_ws, temperature, V);
-    else
-      hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t>), dim3((unsigned)BL), dim3(256), 0, stream, (const bf16_t*)probs, (const bf16_t*)d_out,
-                         (bf16_t*)dlogits_ws, temperature, V);
+    const bool al = ((((uintptr_t)probs) | ((uintptr_t)d_out) | ((uintptr_t)dlogits_ws)) & 15) == 0;
+    if (dt == DT_F32) {
+      if (al && V % 4 == 0 && V <= 256 * 8 * 4)
+        hipLaunchKernelGGL((softmax_bwd_vec_kernel<float, 8>), dim3((unsigned)BL), dim3(256), 0, stream, (const float*)probs, (const float*)d_out,
+                           (float*)dlogits_ws, temperature, V);
+      else
+        hipLaunchKernelGGL((softmax_bwd_kernel<float>), dim3((unsigned)BL), dim3(256), 0, stream, (const float*)probs, (const float*)d_out,
+                           (float*)dlogits_ws, temperature, V);
+    } else {
+      if (al && V % 8 == 0 && V <= 256 * 5 * 8)
+        hipLaunchKernelGGL((softmax_bwd_vec_kernel<bf16_t, 5>), dim3((unsigned)BL), dim3(256), 0, stream, (const bf16_t*)probs, (const bf16_t*)d_out,
+                           (bf16_t*)dlogits_ws, temperature, V);
+      else if (al && V % 8 == 0 && V <= 256 * 8 * 8)
+        hipLaunchKernelGGL((softmax_bwd_vec_kernel<bf16_t, 8>), dim3((unsigned)BL), dim3(256), 0, stream, (const bf16_t*)probs, (const bf16_t*)d_out,
+                           (bf16_t*)dlogits_ws, temperature, V);
+      else
+        hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t>), dim3((unsigned)BL), dim3(256), 0, stream, (const bf16_t*)probs, (const bf16_t*)d_out,
+                           (bf16_t*)dlogits_ws, temperature, V);
+    }
     GIC_CHECK_LAUNCH("softmax_bwd");
   }
   GemmDesc g;

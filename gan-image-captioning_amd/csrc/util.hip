@@ -60,6 +60,50 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, lo
   }
 }
 
+// ---- the same for 16-byte aligned operands: a thread sums 8 (bf16) / 4 (f32) adjacent columns, 16 bytes per load, four rows in flight
+// per thread; block = 32 column groups x 8 row lanes.  (The scalar kernel above keeps one 2-byte load per thread in flight.)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ A, long lda, long rows, long cols,
+                                                           float* __restrict__ out, float* __restrict__ out2) {
+  constexpr int VN = 16 / (int)sizeof(T);
+  __shared__ float red[8][32][VN + 1];
+  const int cg = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const long c0 = ((long)blockIdx.x * 32 + cg) * VN;
+  float s[VN];
+#pragma unroll
+  for (int k = 0; k < VN; ++k) s[k] = 0.f;
+  if (c0 < cols) {
+    const long step = (long)gridDim.y * 8;
+    for (long r = (long)blockIdx.y * 8 + ry; r < rows; r += 4 * step) {
+      T v[4][VN];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long ru = r + u * step;
+        *(uint4*)v[u] = *(const uint4*)(A + (ru < rows ? ru : r) * lda + c0);      // rows past the end re-read row r (weight 0 below)
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float wgt = r + u * step < rows ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < VN; ++k) s[k] += wgt * to_f32<T>(v[u][k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < VN; ++k) red[ry][cg][k] = s[k];
+  __syncthreads();
+  if (ry == 0 && c0 < cols) {
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += red[q][cg][k];
+      atomicAdd(&out[c0 + k], t);
+      if (out2) atomicAdd(&out2[c0 + k], t);
+    }
+  }
+}
+
 __global__ void embedding_fwd_kernel(const float* __restrict__ w, const int64_t* __restrict__ ids, float* __restrict__ out,
                                      long n, int V, int E) {
   const long total = n * E;
@@ -141,6 +185,19 @@ int colsum(const void* A, int dtype, long lda, long rows, long cols, float* out,
     if (out2) GIC_PROPAGATE(fill_zero(out2, cols * sizeof(float), stream));
   }
   if (rows == 0) return GIC_OK;
+  const int vn = 16 / dtype_size(dtype);
+  if (cols % vn == 0 && lda % vn == 0 && (((uintptr_t)A) & 15) == 0) {
+    const int gx = cdiv(cols / vn, 32);
+    int gy = cdiv(rows, 8 * 8);
+    const int want = 2048 / (gx < 1 ? 1 : gx);
+    gy = gy > want ? (want < 1 ? 1 : want) : gy;
+    if (dtype == DT_F32)
+      hipLaunchKernelGGL((colsum_vec_kernel<float>), dim3(gx, gy), dim3(256), 0, stream, (const float*)A, lda, rows, cols, out, out2);
+    else
+      hipLaunchKernelGGL((colsum_vec_kernel<bf16_t>), dim3(gx, gy), dim3(256), 0, stream, (const bf16_t*)A, lda, rows, cols, out, out2);
+    GIC_CHECK_LAUNCH("colsum");
+    return GIC_OK;
+  }
   const int gx = cdiv(cols, 64);
   int gy = cdiv(rows, 4 * 16);
   const int want = 1024 / (gx < 1 ? 1 : gx);
