@@ -41,6 +41,36 @@ __global__ void cast2d_kernel(const TS* __restrict__ src, long lds, TD* __restri
   }
 }
 
+// f32 -> bf16 for 16-byte aligned operands with cols % 8 == 0: a thread converts 8 adjacent columns (two 16-byte loads, one 16-byte store),
+// two such pieces per iteration in flight (the weight images of the compute dtype are refreshed every step: 60 MB of them)
+__global__ __launch_bounds__(256) void cast2d_f32_bf16_vec_kernel(const float* __restrict__ src, long lds, bf16_t* __restrict__ dst, long ldd,
+                                                                  long rows, long cols) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const long cpr = cols / 8, total = rows * cpr;
+  const long S = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += 2 * S) {
+    f4 a[2][2];
+    long o[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long iu = i + u * S < total ? i + u * S : i;
+      const long r = iu / cpr, c = (iu - r * cpr) * 8;
+      o[u] = r * ldd + c;
+      const float* p = src + r * lds + c;
+      a[u][0] = *(const f4*)p;
+      a[u][1] = *(const f4*)(p + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (i + u * S >= total) break;
+      bf16x8 v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] = (bf16_t)a[u][0][k]; v[4 + k] = (bf16_t)a[u][1][k]; }
+      *(bf16x8*)(dst + o[u]) = v;
+    }
+  }
+}
+
 // ---- column sums: block = 64 columns x 4 row-lanes; rows strided over gridDim.y blocks, f32 atomics across them
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, long lda, long rows, long cols,
@@ -162,6 +192,9 @@ int cast2d(const void* src, int sdt, long lds, void* dst, int ddt, long ldd, lon
   const int g = grid_for(rows * cols);
   if (sdt == DT_F32 && ddt == DT_F32)
     hipLaunchKernelGGL((cast2d_kernel<float, float>), dim3(g), dim3(256), 0, stream, (const float*)src, lds, (float*)dst, ldd, rows, cols);
+  else if (sdt == DT_F32 && ddt == DT_BF16 && cols % 8 == 0 && lds % 4 == 0 && ldd % 8 == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0)
+    hipLaunchKernelGGL(cast2d_f32_bf16_vec_kernel, dim3(grid_for(rows * cols / 16)), dim3(256), 0, stream, (const float*)src, lds, (bf16_t*)dst, ldd,
+                       rows, cols);
   else if (sdt == DT_F32 && ddt == DT_BF16)
     hipLaunchKernelGGL((cast2d_kernel<float, bf16_t>), dim3(g), dim3(256), 0, stream, (const float*)src, lds, (bf16_t*)dst, ldd, rows, cols);
   else if (sdt == DT_BF16 && ddt == DT_F32)
