@@ -13,7 +13,7 @@ with open(sys.argv[1]) as fh:
     for row in csv.DictReader(fh):
         name = row["Kernel_Name"]
         # the trunk's convolution kernels: tile8 (implicit GEMM), the patch-resident 3x3, the streaming and the panel-resident 1x1 kernels
-        conv = ("tile8_kernel" in name and "Lb1E" in name) or any(k in name for k in ("conv3x3_patch_kernel", "conv1x1_stream_kernel", "conv1x1_panel_kernel"))
+        conv = ("tile8_kernel" in name and "Lb1E" in name) or any(k in name for k in ("conv3x3_patch_kernel", "conv1x1_stream_kernel", "conv1x1_panel_kernel", "conv_stem_kernel"))
         key = "conv" if conv else ("bn_act" if "bn_act_kernel" in name else None)
         if key is None:
             continue

@@ -14,7 +14,7 @@ def per_kernel(path, counter):
             if row.get("Counter_Name") != counter:
                 continue
             name = row["Kernel_Name"]
-            key = "conv" if ("tile8_kernel" in name or any(k in name for k in ("conv3x3_patch_kernel", "conv1x1_stream_kernel", "conv1x1_panel_kernel"))
+            key = "conv" if ("tile8_kernel" in name or any(k in name for k in ("conv3x3_patch_kernel", "conv1x1_stream_kernel", "conv1x1_panel_kernel", "conv_stem_kernel"))
                              or ("gemm_kernel" in name and "Lb1ELb1ELi" in name and "ELi2ELb1E" in name)) else \
                   "bn_act" if "bn_act_kernel" in name else None
             if key is None:
