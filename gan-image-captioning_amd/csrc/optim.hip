@@ -140,7 +140,18 @@ __global__ __launch_bounds__(kNormBlock) void sqnorm_partial_kernel(const float*
   __shared__ float red[16];
   const long base = (long)blockIdx.x * kNormElemsPerBlock;
   float s = 0.f;
-  for (long i = base + threadIdx.x; i < base + kNormElemsPerBlock && i < n; i += kNormBlock) { const float v = g[i]; s += v * v; }
+  if (base + kNormElemsPerBlock <= n && (((uintptr_t)g) & 15) == 0) {
+    // whole block: four 16-byte loads per thread, all in flight (the scalar loop below keeps one 4-byte load in flight)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* gv = (const f4*)(g + base);
+    f4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = gv[threadIdx.x + kNormBlock * u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
+  } else {
+    for (long i = base + threadIdx.x; i < base + kNormElemsPerBlock && i < n; i += kNormBlock) { const float v = g[i]; s += v * v; }
+  }
   s = block_sum(s, red);
   if (threadIdx.x == 0) {
     partials[blockIdx.x] = s;
@@ -166,13 +177,28 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
   const float omb1 = (float)(1.0 - b1_d), omb2 = (float)(1.0 - b2_d), b2 = (float)b2_d, eps = (float)eps_d;
   const float bc2_sqrt = (float)sqrt(1.0 - pow(b2_d, t));
   const float step_size = (float)(lr_d / (1.0 - pow(b1_d, t)));
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float gi = g[i] * coef;
-    const float mi = m[i] + (gi - m[i]) * omb1;              // exp_avg.lerp_(grad, 1-beta1)
-    const float vi = v[i] * b2 + omb2 * gi * gi;             // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
-    m[i] = mi; v[i] = vi;
+  auto update = [&](float gi, float& mi, float& vi, float& pi) {
+    gi *= coef;
+    mi = mi + (gi - mi) * omb1;                              // exp_avg.lerp_(grad, 1-beta1)
+    vi = vi * b2 + omb2 * gi * gi;                           // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mi / denom);
+    pi = pi - step_size * (mi / denom);
+  };
+  // 16-byte accesses over the aligned body (the four arenas share their alignment: same offsets), scalars over the tail
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const bool al = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+  const long n4 = al ? n / 4 : 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f4 g4 = ((const f4*)g)[i];
+    f4 m4 = ((f4*)m)[i], v4 = ((f4*)v)[i], p4 = ((f4*)p)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { float mi = m4[k], vi = v4[k], pi = p4[k]; update(g4[k], mi, vi, pi); m4[k] = mi; v4[k] = vi; p4[k] = pi; }
+    ((f4*)m)[i] = m4; ((f4*)v)[i] = v4; ((f4*)p)[i] = p4;
+  }
+  for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float mi = m[i], vi = v[i], pi = p[i];
+    update(g[i], mi, vi, pi);
+    m[i] = mi; v[i] = vi; p[i] = pi;
   }
 }
 
