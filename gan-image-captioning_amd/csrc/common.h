@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace gic {
 
@@ -155,6 +156,22 @@ static inline bool grant_lds(Kf kernel, size_t bytes, size_t& granted) {
   }
   granted = bytes;
   return true;
+}
+
+// Workgroups go to the 8 XCDs round-robin (blockIdx.x % 8), each XCD with its own 4 MB L2.  xcd_run() renumbers them so that every XCD owns
+// ONE contiguous run of the returned index, in its dispatch order: workgroups whose returned indices are neighbours run on the same XCD at
+// about the same time, so what they both read (the A rows of one row tile, under its output-channel tiles) comes from HBM / MALL once.
+__device__ __forceinline__ int xcd_run(const int b, const int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+// host side of the choice "which operand do an XCD's concurrent workgroups share": the output-channel tiles of a row tile as neighbours
+// (A once per XCD, every XCD reads all of B) or the row tiles of a channel tile (B once, A once per channel tile).  GIC_XCD_SHARE=a|b forces.
+static inline bool xcd_share_a(const long a_bytes, const long b_bytes, const int tiles_n) {
+  static const int force = [] { const char* e = getenv("GIC_XCD_SHARE"); return !e ? 0 : (*e == 'a' ? 1 : *e == 'b' ? 2 : 0); }();
+  if (tiles_n <= 1) return false;
+  if (force) return force == 1;
+  return a_bytes * (tiles_n - 1) > 7 * b_bytes;
 }
 
 }  // namespace gic

@@ -25,6 +25,7 @@ struct PanelDesc {
   const float* in_stats; const float* in_gamma; const float* in_beta;
   int M, N, lda, ldb, ldc, stats_nrep, in_nrep;
   float in_inv_count;
+  int share_a;
   int tiles_m, tiles_n, groups, per_group;   // row tiles, 64-wide output-channel tiles, groups of them, tiles per group
   unsigned a_bytes, b_bytes;
 };
@@ -47,8 +48,10 @@ __global__ __launch_bounds__(512) void conv1x1_panel_kernel(const PanelDesc d) {
   const int wr = w >> 1, wc = w & 1;
   const int lr = lane & 15, lg = lane >> 4;
   const int M = d.M, N = d.N;
-  // workgroup -> (row tile, group of output-channel tiles): the groups of one row tile are neighbours (they share the A panel in L2)
-  const int grp = blockIdx.x % d.groups, tile_m = blockIdx.x / d.groups;
+  // workgroup -> (row tile, group of output-channel tiles): the groups of one row tile are neighbours on one XCD (they share the A panel
+  // in its L2: xcd_run)
+  const int bid = d.share_a ? xcd_run(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int grp = bid % d.groups, tile_m = bid / d.groups;
   const int bm0 = tile_m * BM;
   const int nt0 = grp * d.per_group;
   const int nt1 = min(nt0 + d.per_group, d.tiles_n);
@@ -225,6 +228,7 @@ bool try_conv1x1_panel(const GemmDesc& d, hipStream_t stream) {
   if (groups > pd.tiles_n) groups = pd.tiles_n;
   pd.per_group = cdiv(pd.tiles_n, groups);
   pd.groups = cdiv(pd.tiles_n, pd.per_group);
+  pd.share_a = xcd_share_a(2l * d.M * d.K, 2l * d.N * d.K, pd.groups);
   pd.A = d.A; pd.B = d.B; pd.C = d.C; pd.stats = d.stats;
   pd.in_stats = d.in_stats; pd.in_gamma = d.in_gamma; pd.in_beta = d.in_beta;
   pd.M = d.M; pd.N = d.N; pd.lda = (int)d.lda; pd.ldb = (int)d.ldb; pd.ldc = (int)d.ldc;

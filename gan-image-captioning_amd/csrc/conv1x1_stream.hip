@@ -28,6 +28,7 @@ struct StreamDesc {
   const float* in_stats; const float* in_gamma; const float* in_beta;
   int M, N, lda, ldb, ldc, stats_nrep, in_nrep;
   float in_inv_count;
+  int share_a;
   int tiles_m, tiles_n, groups;        // row tiles, output-channel tiles, workgroups per output-channel tile (grid = groups * tiles_n)
   unsigned a_bytes, b_bytes;
 };
@@ -52,9 +53,11 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const StreamDesc d)
   const int wr = w >> 1, wc = w & 1;
   const int lr = lane & 15, lg = lane >> 4;
   const int M = d.M, N = d.N;
-  // workgroup -> (output-channel tile, first row tile); consecutive workgroups of one channel tile sit on one XCD (shared weights in L2)
-  const int tile_n = blockIdx.x % d.tiles_n;
-  const int grp = blockIdx.x / d.tiles_n;
+  // workgroup -> (output-channel tile, first row tile): the channel tiles of one row-tile sequence are neighbours on one XCD and walk
+  // their row tiles in step, so each A tile leaves HBM once (share_a; the weights, <= 128 KB, sit in every L2 anyway)
+  const int bid = d.share_a ? xcd_run(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int tile_n = bid % d.tiles_n;
+  const int grp = bid / d.tiles_n;
   const int bn0 = tile_n * BN;
 
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)d.a_bytes, 0x00020000);
@@ -275,6 +278,7 @@ bool try_conv1x1_stream(const GemmDesc& d, hipStream_t stream) {
   if (groups < 1) groups = 1;
   if (groups > sd.tiles_m) groups = sd.tiles_m;
   sd.groups = groups;
+  sd.share_a = xcd_share_a(2l * d.M * d.K, 2l * d.N * d.K, sd.tiles_n);
   sd.A = d.A; sd.B = d.B; sd.C = d.C; sd.stats = d.stats;
   sd.in_stats = d.in_stats; sd.in_gamma = d.in_gamma; sd.in_beta = d.in_beta;
   sd.M = d.M; sd.N = d.N; sd.lda = (int)d.lda; sd.ldb = (int)d.ldb; sd.ldc = (int)d.ldc;

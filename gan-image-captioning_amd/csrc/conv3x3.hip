@@ -67,6 +67,7 @@ struct PatchDesc {
   int M, N, H, W, Cin, ldb, ldc, stats_nrep, in_nrep;
   float in_inv_count;
   int tiles_m;              // row tiles
+  int tiles_n;              // > 0: output-channel tiles, and those of one row tile are neighbours on an XCD; 0: the row tiles of a channel tile are
   int tpi;                  // > 0: tiles never cross an image (tpi tiles per image, the last one short); 0: 128 consecutive rows of M
   int nchunks;              // Cin / 64
   unsigned a_bytes, b_bytes;
@@ -98,13 +99,17 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchDesc d) {
   const int PH = H + 2, PW = W + 2, HW = H * W;
 
   const float iPW = 1.f / (float)PW, iPH = 1.f / (float)PH, iHW = 1.f / (float)HW, iW = 1.f / (float)W;
-  int bid = blockIdx.x;
-  {  // consecutive row tiles of one output-channel tile share an XCD's L2 (as tile8)
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  // neighbours on one XCD (xcd_run): the output-channel tiles of one row tile (tiles_n > 0: the patch leaves HBM once) or, as tile8's
+  // default, consecutive row tiles of one channel tile (the weights once)
+  const int bid = xcd_run(blockIdx.x, gridDim.x);
+  int tile_n, tile_m;
+  if (pa.tiles_n > 0) {
+    tile_m = fdiv(bid, pa.tiles_n, 1.f / (float)pa.tiles_n);
+    tile_n = bid - tile_m * pa.tiles_n;
+  } else {
+    tile_n = fdiv(bid, pa.tiles_m, 1.f / (float)pa.tiles_m);
+    tile_m = bid - tile_n * pa.tiles_m;
   }
-  const int tile_n = fdiv(bid, pa.tiles_m, 1.f / (float)pa.tiles_m);
-  const int tile_m = bid - tile_n * pa.tiles_m;
   const int bn0 = tile_n * BN;
   int bm0, mlim;
   if (pa.tpi > 0) {
@@ -407,6 +412,8 @@ bool try_conv3x3_patch(const GemmDesc& d, hipStream_t stream) {
   const bool n128 = d.N >= 128 && (long)pa.tiles_m * cdiv(d.N, 128) >= 160;
   const long tiles = (long)pa.tiles_m * (n128 ? cdiv(d.N, 128) : cdiv(d.N, 64));
   pa.a_bytes = (unsigned)(a_elems * 2); pa.b_bytes = (unsigned)(b_elems * 2);
+  const int tiles_n = n128 ? cdiv(d.N, 128) : cdiv(d.N, 64);
+  pa.tiles_n = xcd_share_a(a_elems * 2, b_elems * 2, tiles_n) ? tiles_n : 0;
   if (abn) return n128 ? pick_patch<128, true>(pa, P, tiles, stream) : pick_patch<64, true>(pa, P, tiles, stream);
   return n128 ? pick_patch<128, false>(pa, P, tiles, stream) : pick_patch<64, false>(pa, P, tiles, stream);
 }

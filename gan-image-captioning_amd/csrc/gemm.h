@@ -60,6 +60,7 @@ struct GemmDesc {
   const float* res_gamma = nullptr; const float* res_beta = nullptr;
   float res_inv_count = 0.f;
   void* out_wb = nullptr;
+  int n_fast = 0;           // tile8: the output-channel tiles of a row tile are neighbours on one XCD (xcd_share_a) instead of the row tiles of a channel tile
   int dbg = 0;              // phase-ablation knob, honoured only by -DGIC_STAMPS tool builds
 };
 

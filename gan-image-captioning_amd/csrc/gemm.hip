@@ -553,14 +553,10 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
   const int wr = w >> 1, wc = w & 1;
   const int lr = lane & 15, lg = lane >> 4;
 
-  const int tiles_m = (d.M + BM - 1) / BM;
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-  }
-  const int bm0 = (bid % tiles_m) * BM;
-  const int bn0 = (bid / tiles_m) * BN;
+  const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
+  const int bid = xcd_run(blockIdx.x, gridDim.x);
+  const int bm0 = (d.n_fast ? bid / tiles_n : bid % tiles_m) * BM;
+  const int bn0 = (d.n_fast ? bid % tiles_n : bid / tiles_m) * BN;
   const int M = d.M, N = d.N, K = d.K;
 
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, (int)a_bytes, 0x00020000);
@@ -1003,8 +999,9 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
 // Launch the 8-wave kernel if the product qualifies (bf16 k-contiguous operands under 2 GiB each, a plain / BatchNorm-sum
 // epilogue that overwrites a 16-byte-aligned C); returns false to fall back to gemm_kernel.
 template <typename TO, int EPI, bool CONV>
-bool try_tile8(const GemmDesc& d, hipStream_t stream) {
+bool try_tile8(const GemmDesc& d_in, hipStream_t stream) {
   static const bool off = getenv("GIC_NO_TILE8") != nullptr;
+  GemmDesc d = d_in;
   constexpr int OVE = 16 / (int)sizeof(TO);
   if (off || d.M < 128) return false;
   if (EPI != EPI_HIGHWAY && ((d.N % OVE) || (d.ldc % OVE) || (((uintptr_t)d.C) & 15))) return false;
@@ -1020,6 +1017,8 @@ bool try_tile8(const GemmDesc& d, hipStream_t stream) {
   static const int min_nk = [] { const char* e = getenv("GIC_TILE8_MIN_NK"); return e ? atoi(e) : 1; }();
   if (cdiv(d.K, 64) < min_nk) return false;
   const unsigned ab = (unsigned)(a_elems * 2), bb = (unsigned)(b_elems * 2);
+  // what an XCD's concurrent workgroups share (common.h): A bytes actually gathered (a strided 1x1 touches 1 / stride^2 of its input)
+  d.n_fast = xcd_share_a(2 * (a_elems < (long)d.M * d.K ? a_elems : (long)d.M * d.K), 2l * d.N * d.K, cdiv(d.N, d.N >= 128 ? 128 : 64));
   // deep ring (4 stages, 128 KB: one block per CU) when the grid is about one block per CU; with several blocks per CU a
   // 2-stage ring (64 KB) lets two blocks share the CU so one block's epilogue runs under the other's K loop
   if constexpr (EPI == EPI_BNSTATS && CONV) {
