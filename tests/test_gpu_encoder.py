@@ -60,7 +60,8 @@ CONV_CASES = [  # (N, Cin, H, Cout, k, stride, pad)
     # row tail, K = 64 / 256 output channels, K = 128 / 512 output channels
     (41, 64, 56, 96, 1, 1, 0), (40, 64, 56, 256, 1, 1, 0), (44, 128, 28, 512, 1, 1, 0),
     # the A-panel-resident 1x1 kernel (conv1x1_panel.hip; K = 256, >= 512 output channels): a row tail, groups of channel tiles
-    (5, 256, 14, 1024, 1, 1, 0), (64, 256, 14, 512, 1, 1, 0),
+    # ... and a short last row tile whose workgroups walk four channel tiles each
+    (5, 256, 14, 1024, 1, 1, 0), (64, 256, 14, 512, 1, 1, 0), (33, 256, 14, 1024, 1, 1, 0),
 ]
 
 
@@ -465,7 +466,7 @@ def test_cold_and_mispredicted_trunk_passes_do_not_race_the_lookahead(dev):
                                   (3, 9, 72, 40, 1, 1, 0), (4, 28, 128, 128, 3, 1, 1), (4, 28, 128, 128, 3, 2, 1), (8, 56, 64, 64, 3, 1, 1),
                                   (16, 14, 256, 256, 3, 1, 1), (8, 7, 512, 512, 3, 1, 1), (2, 12, 192, 96, 3, 1, 1),
                                   (40, 56, 64, 256, 1, 1, 0), (44, 28, 128, 512, 1, 1, 0), (41, 56, 64, 96, 1, 1, 0),
-                                  (5, 14, 256, 1024, 1, 1, 0), (64, 14, 256, 1024, 1, 1, 0)])
+                                  (5, 14, 256, 1024, 1, 1, 0), (64, 14, 256, 1024, 1, 1, 0), (33, 14, 256, 1024, 1, 1, 0)])
 def test_conv_with_input_batchnorm_equals_bn_act_then_conv(dev, case):
     """gic_conv2d_bn_in (bn + ReLU applied to the A tiles in LDS, padding taps left at zero) against gic_bn_act followed by
     gic_conv2d on the same raw tensor and statistics: same bf16 input to the MFMAs, so outputs and column sums agree to rounding."""
