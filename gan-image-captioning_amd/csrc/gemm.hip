@@ -1112,6 +1112,9 @@ int launch(const GemmDesc& d, hipStream_t stream) {
       splits = 512 / tiles;
       if (splits > nk / 8) splits = nk / 8;
       if (splits > 16) splits = 16;
+    } else if (!AKC && !BKC && tiles <= 192 && nk >= 16) {   // weight-gradient form (both operands row-major over K = B*L rows) over few tiles:
+      splits = 512 / tiles;                      // the D embedding gradient, 157 tiles x K = 1280
+      if (splits > nk / 4) splits = nk / 4;
     } else if (tiles <= 320 && nk >= 64) {       // about one 4-wave block per CU over a very deep K (the highway weight gradient: 225 tiles,
       splits = 768 / tiles;                      // K = 2B*R = 8192): ~3 blocks per CU, 87 -> 47 us (tools/gemm_hw_bench.py)
     }
