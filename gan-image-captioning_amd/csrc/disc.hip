@@ -361,6 +361,55 @@ __global__ __launch_bounds__(256) void disc_conv_pool_bwd_w_kernel(const float* 
   }
 }
 
+// The same for s == 1 with the embedding columns of one caption staged in LDS as xs[representation][t]: the eight taps of a
+// (pair, filter) are then LDS reads of one 20-float row (lanes = filters of one pair: broadcast / few banks) instead of eight
+// scattered 4-byte global loads at stride De (one address per lane per load kept the texture path busy for 82 us at cfg2; the
+// streams pooled / dpooled / argmax are 55 MB): 41 us.  block = 64 filters x 4 waves over the representations, captions over
+// gridDim.y.  (Four filters per thread -- a quarter of the load instructions, 16-byte loads -- took 62-74 us: the kernel lives on
+// the number of waves in flight, not on the load count.)
+template <typename TA, int MAXT>
+__global__ __launch_bounds__(256) void disc_conv_pool_bwd_w_lds_kernel(const float* __restrict__ dpooled, const TA* __restrict__ pooled,
+                                                                         const uint8_t* __restrict__ argmax, const float* __restrict__ emb,
+                                                                         ConvMeta cm, int L, int De, int R, int ncap) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];       // [R][LP], LP = L + MAXT | 1 (zero beyond L)
+  __shared__ float red[4][64][MAXT + 1];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int LP = (L + MAXT) | 1;
+  const int col = blockIdx.x * 64 + cx;
+  const bool okc = col < cm.F;
+  const int colc = okc ? col : 0;
+  float acc[MAXT + 1];
+#pragma unroll
+  for (int j = 0; j <= MAXT; ++j) acc[j] = 0.f;
+  const int k = conv_of(cm, colc), taps = cm.fsize[k], ch = colc - cm.foff[k];
+  for (int i = threadIdx.x; i < R * LP; i += 256) xs[i] = 0.f;
+  for (int b = blockIdx.y; b < ncap; b += gridDim.y) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * L; i += 256) {
+      const int t = i / R, r = i - t * R;
+      xs[r * LP + t] = emb[((long)b * L + t) * De + r];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = ry; r < R; r += 4) {
+      const long o = ((long)b * R + r) * cm.Fp + colc;
+      const float g = (okc && to_f32<TA>(pooled[o]) > 0.f) ? dpooled[o] : 0.f;     // relu gate
+      const float* x = xs + r * LP + argmax[o];                      // the window starts at the argmax (<= L - width)
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) acc[j] += g * x[j];             // taps beyond the width: dropped when the sums leave
+      acc[MAXT] += g;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j <= MAXT; ++j) red[ry][cx][j] = acc[j];
+  __syncthreads();
+  if (ry == 0 && okc) {
+    for (int j = 0; j < taps; ++j)
+      atomicAdd(&cm.dw[k][(long)ch * taps + j], red[0][cx][j] + red[1][cx][j] + red[2][cx][j] + red[3][cx][j]);
+    atomicAdd(&cm.db[k][ch], red[0][cx][MAXT] + red[1][cx][MAXT] + red[2][cx][MAXT] + red[3][cx][MAXT]);
+  }
+}
+
 // ---- logits[m] = feat[m,:] . w + b   (out2logits, discriminator.py:60)
 __global__ void disc_out_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ bias,
                                     float* __restrict__ logits, long rows) {
@@ -623,7 +672,13 @@ int disc_bwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
     gy = gy > 64 ? 64 : gy;
     int mt = 0;
     for (int k = 0; k < c.cm.nconv; ++k) mt = c.cm.fsize[k] * c.s > mt ? c.cm.fsize[k] * c.s : mt;
-    if (mt <= 8)
+    static const bool no_lds = getenv("GIC_NO_DISC_BWDW_LDS") != nullptr;
+    if (mt <= 8 && c.s == 1 && c.R <= 64 && c.R <= c.De && MR % c.R == 0 && c.L <= 64 && !no_lds) {
+      const int ncap = (int)(MR / c.R);
+      hipLaunchKernelGGL((disc_conv_pool_bwd_w_lds_kernel<TA, 8>), dim3(cdiv(c.F, 64), ncap < 64 ? ncap : 64), dim3(256),
+                         (size_t)c.R * ((c.L + 8) | 1) * sizeof(float), stream, (const float*)ws->dpooled, (const TA*)st->pooled,
+                         (const uint8_t*)st->argmax, (const float*)st->emb, c.cm, c.L, c.De, c.R, ncap);
+    } else if (mt <= 8)
       hipLaunchKernelGGL((disc_conv_pool_bwd_w_kernel<TA, 8>), dim3(cdiv(c.F, 64), gy), dim3(256), 0, stream, (const float*)ws->dpooled,
                          (const TA*)st->pooled, (const uint8_t*)st->argmax, (const float*)st->emb, c.cm, c.L, c.De, c.R, MR);
     else
