@@ -1231,6 +1231,12 @@ int gemm(const GemmDesc& d0, hipStream_t stream) {
   GIC_CHECK_ARG(d.A && d.B && d.C, "gemm: null operand");
   GIC_CHECK_ARG(d.M >= 0 && d.N >= 0 && d.K >= 0, "gemm: negative dim");
   if (d.M == 0 || d.N == 0) return GIC_OK;
+  {  // GIC_GEMM_LOG=1: one line per product on stderr (tools: which shapes a step issues)
+    static const bool log = getenv("GIC_GEMM_LOG") != nullptr;
+    if (log && !d.conv)
+      fprintf(stderr, "[gemm] M=%d N=%d K=%d a_kc=%d b_kc=%d in=%d out=%d epi=%d acc=%d\n", d.M, d.N, d.K, d.a_kc, d.b_kc, d.in_dtype, d.out_dtype, d.epi,
+              d.accumulate);
+  }
   if (d.epi == EPI_HIGHWAY) GIC_CHECK_ARG(d.X, "gemm: highway epilogue needs X");      // Hpre may be null (forward only)
   const int sz = dtype_size(d.in_dtype);
   const int ve = 16 / sz;
