@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void disc_conv_pool_bwd_w_kernel(const float* 
 // The same for s == 1 with the embedding columns of one caption staged in LDS as xs[representation][t]: the eight taps of a
 // (pair, filter) are then LDS reads of one 20-float row (lanes = filters of one pair: broadcast / few banks) instead of eight
 // scattered 4-byte global loads at stride De (one address per lane per load kept the texture path busy for 82 us at cfg2; the
-// streams pooled / dpooled / argmax are 55 MB): 41 us.  block = 64 filters x 4 waves over the representations, captions over
+// streams pooled / dpooled / argmax are 55 MB): 27 us.  block = 64 filters x 4 waves over the representations, captions over
 // gridDim.y.  (Four filters per thread -- a quarter of the load instructions, 16-byte loads -- took 62-74 us: the kernel lives on
 // the number of waves in flight, not on the load count.)
 template <typename TA, int MAXT>
@@ -397,14 +397,29 @@ __global__ __launch_bounds__(256) void disc_conv_pool_bwd_w_lds_kernel(const flo
       xs[r * LP + t] = emb[((long)b * L + t) * De + r];
     }
     __syncthreads();
-#pragma unroll 4
-    for (int r = ry; r < R; r += 4) {
-      const long o = ((long)b * R + r) * cm.Fp + colc;
-      const float g = (okc && to_f32<TA>(pooled[o]) > 0.f) ? dpooled[o] : 0.f;     // relu gate
-      const float* x = xs + r * LP + argmax[o];                      // the window starts at the argmax (<= L - width)
+    // eight pairs per pass: their 24 loads leave together (clamped rows, masked afterwards), then the LDS windows.  The relu gate is a
+    // 0 / 1 factor: a select lets the compiler sink the dpooled load under the pooled test (two dependent round trips per pair).
+    constexpr int U = 8;
+    for (int r0 = ry; r0 < R; r0 += 4 * U) {
+      float pv[U], dg[U];
+      int tt[U], rc[U];
 #pragma unroll
-      for (int j = 0; j < MAXT; ++j) acc[j] += g * x[j];             // taps beyond the width: dropped when the sums leave
-      acc[MAXT] += g;
+      for (int u = 0; u < U; ++u) {
+        const int r = r0 + 4 * u;
+        rc[u] = r < R ? r : R - 1;
+        const long o = ((long)b * R + rc[u]) * cm.Fp + colc;
+        pv[u] = to_f32<TA>(pooled[o]);
+        dg[u] = dpooled[o];
+        tt[u] = argmax[o];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float g = dg[u] * ((okc && r0 + 4 * u < R && pv[u] > 0.f) ? 1.f : 0.f);
+        const float* x = xs + rc[u] * LP + tt[u];                    // the window starts at the argmax (<= L - width)
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) acc[j] += g * x[j];           // taps beyond the width: dropped when the sums leave
+        acc[MAXT] += g;
+      }
     }
   }
 #pragma unroll
