@@ -280,7 +280,8 @@ template <typename TA, int MAXO, int MAXT>
 __global__ __launch_bounds__(256) void disc_conv_pool_bwd_x_small_kernel(const float* __restrict__ dpooled, const TA* __restrict__ pooled,
                                                                            const uint8_t* __restrict__ argmax, ConvMeta cm, int L, int De,
                                                                            int R, TA* __restrict__ demb, int rows, int rpb) {
-  __shared__ float part[MAXO][256];
+  extern __shared__ __attribute__((aligned(16))) float part_raw[];     // [n_out][256] (n_out <= MAXO): 20 KB at L = 20, eight workgroups per CU
+  float (*part)[256] = (float (*)[256])part_raw;
   const int s = cm.s, n_out = L * s;
   constexpr int FPT = 4;                             // filters per thread (F <= 1024)
   int f_taps[FPT];
@@ -718,7 +719,7 @@ int disc_bwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
   if (n_out <= 32 && c.F <= 1024 && max_taps_x <= 8) {
     static const int rpb_env = [] { const char* e = getenv("GIC_BWDX_RPB"); return e ? atoi(e) : 0; }();
     const int rpb = rpb_env > 0 ? rpb_env : (MR >= 2048 ? 4 : 1);                // rows per block
-    hipLaunchKernelGGL((disc_conv_pool_bwd_x_small_kernel<TA, 32, 8>), dim3((unsigned)cdiv(MR, rpb)), dim3(256), 0, stream,
+    hipLaunchKernelGGL((disc_conv_pool_bwd_x_small_kernel<TA, 32, 8>), dim3((unsigned)cdiv(MR, rpb)), dim3(256), (size_t)n_out * 256 * sizeof(float), stream,
                        (const float*)ws->dpooled, (const TA*)st->pooled, (const uint8_t*)st->argmax, c.cm, c.L, c.De, c.R,
                        (TA*)ws->demb, (int)MR, rpb);
   } else {
