@@ -43,14 +43,14 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=30)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--batch", type=int, default=CFG2["B"], help="captions per GPU per step")
+    p.add_argument("--batch", type=int, default=None, help="captions per GPU per step (default: 64 for cfg2, 32 for cfg4 / cfg5)")
     p.add_argument("--cgan", type=int, default=None, help="1: image-conditional (encoder in the step); default: 1 if the encoder is built")
     p.add_argument("--encoder", default="resnet50", choices=["resnet18", "resnet50"])
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--step-impl", default="fused", choices=["fused", "autograd"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true", help="skip the roofline probe (profiling runs: only the timed steps' kernels)")
-    p.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-oracle steps per leg (after one warm-up)")
+    p.add_argument("--cpu-steps", type=int, default=20, help="timed CPU-oracle steps (after one warm-up; BASELINE.md section 2: median of >= 20)")
     p.add_argument("--no-prefetch", action="store_true", help="do not hand the next batch's images to the step (no trunk prefetch)")
     p.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
                    help="cfg2 (default, the headline: BASELINE configs[1..2], 64 captions/GPU); cfg4: visual-attention decoder, 32 captions/GPU; "
@@ -172,8 +172,8 @@ def cpu_baseline(a, cgan):
     encoder in the step (the headline workload) and without it (the part the reference itself owns: torchvision's trunk is not in
     the reference tree)."""
     from oracle import cpu_step as O
-    # host cores actually usable here: the affinity mask, capped at the 16-core share of a 1-GPU box
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    # BASELINE.md section 2: all host cores of the box (the affinity mask of this process: what it may actually use)
+    cores = len(os.sched_getaffinity(0))
     torch.set_num_threads(cores)
     import statistics
     g = torch.Generator().manual_seed(1008)
@@ -235,8 +235,8 @@ def self_launch(a) -> int:
 
 def main():
     a = parse()
-    if a.workload != "cfg2" and a.batch == CFG2["B"]:
-        a.batch = 32                           # BASELINE configs[3], [4]: global batch 256 over 8 GPUs
+    if a.batch is None:                        # BASELINE configs[1..2]: 64 per GPU; configs[3], [4]: global batch 256 over 8 GPUs
+        a.batch = CFG2["B"] if a.workload == "cfg2" else 32
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         raise SystemExit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))

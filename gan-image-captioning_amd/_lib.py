@@ -135,6 +135,7 @@ _SIGNATURES = {
                                          _P(DecoderBwdWs), c_void_p, c_void_p, c_void_p, C.c_float, C.c_int,
                                          _P(DecoderGrads), C.c_int, c_void_p]),
     "gic_debug_decoder_step": (None, [C.c_int]),
+    "gic_decoder_fused_rollout_rows": (C.c_int, [_P(DecoderDims), c_void_p]),
     "gic_attn_prepare": (C.c_int, [_P(AttnDims), _P(AttnParams), _P(AttnShadow), c_void_p]),
     "gic_attn_sample_fwd": (C.c_int, [_P(AttnDims), _P(AttnParams), _P(AttnShadow), _P(AttnState), c_void_p, c_void_p, c_void_p, C.c_uint64,
                                       C.c_float, C.c_int, c_void_p, c_void_p, c_void_p]),
@@ -172,6 +173,7 @@ _SIGNATURES = {
                                 C.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
+ABI_VERSION = 3               # GIC_ABI_VERSION of include/gicap.h
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 
@@ -201,8 +203,8 @@ def load() -> C.CDLL:
             raise GicError(f"{path} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = argtypes
-    if lib.gic_abi_version() != 2:
-        raise GicError(f"ABI version mismatch: library {lib.gic_abi_version()}, binding 2")
+    if lib.gic_abi_version() != ABI_VERSION:
+        raise GicError(f"ABI version mismatch: library {lib.gic_abi_version()}, binding {ABI_VERSION}")
     _lib = lib
     return lib
 

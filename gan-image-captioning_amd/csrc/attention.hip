@@ -232,18 +232,6 @@ int check_attn_dims(const gic_attn_dims* d, ACtx& c) {
   return GIC_OK;
 }
 
-template <typename K>
-int grant_lds(K kernel, size_t bytes, size_t& granted) {
-  if (bytes <= granted) return GIC_OK;
-  if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-    (void)hipGetLastError();
-    set_last_error("attention kernel: cannot reserve %zu bytes of LDS", bytes);
-    return GIC_ERR_LAUNCH;
-  }
-  granted = bytes;
-  return GIC_OK;
-}
-
 template <typename TA>
 int attn_fwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S, const gic_attn_state* st, const float* features,
                const void* fmap, const float* noise_u, uint64_t seed, float temperature, int pretrain, void* out, int64_t* ids,
@@ -267,8 +255,11 @@ int attn_fwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S
   unsigned long long* rowkey = (unsigned long long*)(st->part + ((2 * per + 1) & ~1l));
   GIC_PROPAGATE(fill_zero(rowkey, (size_t)L * B * sizeof(unsigned long long), stream));
   const size_t lds = (size_t)(c.A + c.P) * sizeof(float);
-  static size_t granted = 64 * 1024;
-  GIC_PROPAGATE(grant_lds(attn_fwd_kernel<TA>, lds, granted));
+  static LdsGrant granted;
+  if (!grant_lds(attn_fwd_kernel<TA>, lds, granted)) {
+    set_last_error("attention kernel: cannot reserve %zu bytes of LDS", lds);
+    return GIC_ERR_LAUNCH;
+  }
   for (int t = 0; t < L; ++t) {
     TA* xh_t = (TA*)st->xh + (long)t * B * ld;
     {  // hp [B, A] = h_{t-1} W_h^T for all captions: one product

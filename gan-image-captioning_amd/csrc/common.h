@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <mutex>
 
 namespace gic {
 
@@ -144,17 +145,28 @@ struct Philox {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// Dynamic LDS beyond 64 KB must be granted per kernel (hipFuncAttributeMaxDynamicSharedMemorySize).  `granted` = what the kernel
-// already has: one static per kernel instantiation at the call site, so the attribute is set once (outside any stream capture: every
-// plan runs its first pass eagerly).  false: the runtime refused (the caller falls back or reports).
+// Dynamic LDS beyond 64 KB must be granted per kernel AND per device (hipFuncAttributeMaxDynamicSharedMemorySize).  LdsGrant = what the
+// kernel already has on each device: one static per kernel instantiation at the call site, so the attribute is set once per device
+// (outside any stream capture: every plan runs its first pass eagerly).  The slow path is serialised, so two host threads that need
+// different sizes cannot leave the smaller one in force.  false: the runtime refused (the caller falls back or reports).
+struct LdsGrant {
+  static constexpr int kMaxDev = 16;
+  size_t by_dev[kMaxDev];
+  std::mutex mu;
+  LdsGrant() { for (size_t& g : by_dev) g = 64 * 1024; }
+};
 template <typename Kf>
-static inline bool grant_lds(Kf kernel, size_t bytes, size_t& granted) {
-  if (bytes <= granted) return true;
+static inline bool grant_lds(Kf kernel, size_t bytes, LdsGrant& g) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LdsGrant::kMaxDev) { (void)hipGetLastError(); dev = -1; }
+  if (dev >= 0 && bytes <= __atomic_load_n(&g.by_dev[dev], __ATOMIC_ACQUIRE)) return true;
+  std::lock_guard<std::mutex> lock(g.mu);
+  if (dev >= 0 && bytes <= g.by_dev[dev]) return true;
   if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
     (void)hipGetLastError();
     return false;
   }
-  granted = bytes;
+  if (dev >= 0) __atomic_store_n(&g.by_dev[dev], bytes, __ATOMIC_RELEASE);     // an unknown device index: set every time
   return true;
 }
 

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512) void conv1x1_panel_kernel(const PanelDesc d) {
 template <int KT, bool ABN>
 bool launch_panel(const PanelDesc& pd, hipStream_t stream) {
   constexpr size_t lds = (size_t)KT * 128 * 128 + 2 * (size_t)KT * 64 * 128 + 128 * (64 * 2 + 16) + 8 * 32 * 2 * 4 + (ABN ? 64 * KT * 8 : 0);
-  static size_t granted = 64 * 1024;
+  static LdsGrant granted;
   if (!grant_lds(conv1x1_panel_kernel<KT, ABN>, lds, granted)) return false;
   hipLaunchKernelGGL((conv1x1_panel_kernel<KT, ABN>), dim3((unsigned)(pd.tiles_m * pd.groups)), dim3(512), lds, stream, pd);
   return true;

@@ -245,7 +245,7 @@ template <int BN, int KT, bool ABN>
 bool launch_stream(const StreamDesc& sd, hipStream_t stream) {
   constexpr int NS = KT == 1 ? 4 : 2;
   constexpr size_t lds = (size_t)NS * KT * 128 * 128 + (size_t)KT * BN * 128 + (KT == 1 ? 2 : 1) * 128 * (BN * 2 + 16) + 4 * BN * 2 * 4 + (ABN ? 64 * KT * 8 : 0);
-  static size_t granted = 64 * 1024;
+  static LdsGrant granted;
   if (!grant_lds(conv1x1_stream_kernel<BN, KT, ABN>, lds, granted)) return false;
   hipLaunchKernelGGL((conv1x1_stream_kernel<BN, KT, ABN>), dim3((unsigned)(sd.groups * sd.tiles_n)), dim3(512), lds, stream, sd);
   return true;

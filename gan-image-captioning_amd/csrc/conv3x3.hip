@@ -364,7 +364,7 @@ template <int BN, int P, bool MULTI, bool ABN>
 bool launch_patch(const PatchDesc& pd, long tiles, hipStream_t stream) {
   constexpr size_t core = (size_t)(MULTI ? 2 : 1) * P * 8192 + 3 * BN * 128;
   const size_t lds = core + (ABN ? (size_t)pd.Cin * 8 : 0);
-  static size_t granted = 64 * 1024;
+  static LdsGrant granted;
   if (!grant_lds(conv3x3_patch_kernel<BN, P, MULTI, ABN>, lds, granted)) return false;
   hipLaunchKernelGGL((conv3x3_patch_kernel<BN, P, MULTI, ABN>), dim3((unsigned)tiles), dim3(512), lds, stream, pd);
   return true;

@@ -168,7 +168,7 @@ bool try_conv_stem(const GemmDesc& d, hipStream_t stream) {
   sd.stats_nrep = d.stats_nrep < 1 ? 1 : d.stats_nrep;
   sd.a_bytes = (unsigned)(a_elems * 2); sd.b_bytes = (unsigned)(b_elems * 2);
   constexpr size_t lds = (size_t)kRing * kSlot + 7 * 4 * 64 * 16 + 2 * 128 * (64 * 2 + 16) + 2 * 64 * 2 * 4;
-  static size_t granted = 64 * 1024;
+  static LdsGrant granted;
   if (!grant_lds(conv_stem_kernel, lds, granted)) return false;
   hipLaunchKernelGGL(conv_stem_kernel, dim3((unsigned)(sd.Nimg * sd.ranges)), dim3(512), lds, stream, sd);
   return true;

@@ -325,14 +325,17 @@ __global__ void build_wcat_kernel(const float* __restrict__ w_ih, const float* _
 }
 
 // Resumed roll-outs: rows [r0, r1) join at this step with the recurrent state of caption r % srcB of an earlier call (one slot of
-// its XH and c buffers): row copies of `rowbytes` (16-byte pieces) and H floats.
+// its XH and c buffers): row copies of `rowbytes` in pieces of PB bytes (16 where the row size allows it, else 4 or 2: a bf16 row
+// of (E + H) % 8 != 0 elements is not a whole number of 16-byte pieces) and H floats.
+template <int PB>
 __global__ void rollout_join_kernel(const unsigned char* __restrict__ src_xh, unsigned char* __restrict__ dst_xh, long rowbytes,
                                     const float* __restrict__ src_c, float* __restrict__ dst_c, int H, long r0, long r1, int srcB) {
-  const long pieces = rowbytes / 16;
+  typedef typename std::conditional<PB == 16, uint4, typename std::conditional<PB == 4, uint32_t, uint16_t>::type>::type piece_t;
+  const long pieces = rowbytes / PB;
   const long total = (r1 - r0) * pieces;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = r0 + i / pieces, p = i % pieces;
-    *(uint4*)(dst_xh + r * rowbytes + p * 16) = *(const uint4*)(src_xh + (r % srcB) * rowbytes + p * 16);
+    *(piece_t*)(dst_xh + r * rowbytes + p * PB) = *(const piece_t*)(src_xh + (r % srcB) * rowbytes + p * PB);
   }
   const long totc = (r1 - r0) * H;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < totc; i += (long)gridDim.x * blockDim.x) {
@@ -384,48 +387,10 @@ int sample_fwd_fused(const Ctx& c, const gic_decoder_params* P, const gic_decode
   float* part_m = st->part;
   float* part_s = st->part + per;
   unsigned long long* rowkey = (unsigned long long*)(st->part + ((2 * per + 1) & ~1l));      // [L][B], 8-byte aligned
-  unsigned int* sync = (unsigned int*)(rowkey + (long)L * B);                                // [2] persistent kernel: barrier counter, error flag
-  // atomicMax targets start below every key; the sync words start at zero
-  GIC_PROPAGATE(fill_zero(rowkey, (size_t)L * B * sizeof(unsigned long long) + 2 * sizeof(unsigned int), stream));
+  // atomicMax targets start below every key
+  GIC_PROPAGATE(fill_zero(rowkey, (size_t)L * B * sizeof(unsigned long long), stream));
   const bool keep = !(opt && opt->no_state);
-  const bool persistent = rollout_persistent_supported(c.dt, B, V, c.E, H, NL);
-  if (persistent) {
-    // ONE launch for all L steps (decoder_step.h): the arguments of step 0 and the strides between steps
-    const long ld = c.ldx(0);
-    RolloutArgs r;
-    LstmStepArgs& a = r.l0;
-    a.xh_t = st->xh[0]; a.xh_next = (TA*)st->xh[0] + (long)B * ld;
-    a.wcat = S->wcat[0]; a.bsum = S->bsum[0];
-    a.c_prev = st->c[0]; a.c_new = st->c[0] + (long)B * H;
-    a.gates = keep ? st->gates[0] : nullptr;
-    if (st->hout) { a.h_out = st->hout; a.ld_out = (long)L * H; }
-    a.B = B; a.H = H; a.din = c.din(0); a.ldx = ld;
-    a.embed = P->embed; a.V = V;
-    if (opt && opt->force_ids) { a.force_ids = opt->force_ids; a.force_stride = L; a.force_len = opt->force_len; }
-    VocabStepArgs& v = r.v0;
-    v.h = (TA*)st->xh[0] + (long)B * ld + c.din(0); v.ldh = ld;
-    v.wout = S->wout; v.bias = P->b_out;
-    v.u = noise_u;
-    v.seed = seed; v.rng_stream = 0; v.temperature = temperature; v.pretrain = pretrain;
-    v.out = out; v.out_stride = (long)L * V;
-    v.part_m = part_m; v.part_s = part_s; v.rowkey = rowkey;
-    v.nblk = nblk; v.B = B; v.V = V; v.H = H;
-    r.L = L;
-    r.xh_step = (long)B * ld * (long)sizeof(TA);
-    r.c_step = (long)B * H;
-    r.gates_step = (long)B * 4 * H;
-    r.hout_step = (long)H * (long)sizeof(TA);
-    r.out_step = (long)V * (long)sizeof(TA);
-    r.part_step = (long)B * nblk;
-    r.u_step = (long)B * V;
-    r.rowkey0 = rowkey;
-    r.sync = sync;
-    const int by = cdiv(B, kStepRows);
-    r.grid_lx = cdiv(H, kUnitsPerBlock); r.grid_l = r.grid_lx * by;
-    r.grid_vx = nblk; r.grid_v = nblk * by;
-    GIC_PROPAGATE(rollout_persistent(r, c.dt, stream));
-  }
-  for (int t = 0; t < L && !persistent; ++t) {
+  for (int t = 0; t < L; ++t) {
     for (int l = 0; l < NL; ++l) {
       const long ld = c.ldx(l);
       LstmStepArgs a;
@@ -461,7 +426,6 @@ int sample_fwd_fused(const Ctx& c, const gic_decoder_params* P, const gic_decode
   f.pretrain = pretrain; f.out = out; f.ids = ids;
   if (opt && opt->force_ids) { f.force_ids = opt->force_ids; f.force_len = opt->force_len; }
   if (keep) { f.embed = P->embed; f.xh0 = st->xh[0]; f.ldx0 = c.ldx(0); }
-  if (persistent) f.err = sync + 1;
   return sample_finish(f, c.dt, stream);
 }
 
@@ -474,8 +438,7 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
   GIC_PROPAGATE(init_slot0(c, st, features, opt, stream));
   // up to a few hundred rows the per-step products are latency-bound: the fused step kernels; beyond that (Monte-Carlo
   // roll-out batches) they are large GEMMs and the generic 128-row-tile kernels are the efficient form
-  static const int fused_max_rows = [] { const char* e = getenv("GIC_FUSED_ROLLOUT_MAX_ROWS"); return e ? atoi(e) : 512; }();
-  if (st->part && B <= fused_max_rows && !(opt && opt->resume_from) && decoder_step_supported(c.dt, V, E, H, NL))
+  if (st->part && B <= decoder_step_max_rows() && !(opt && opt->resume_from) && decoder_step_supported(c.dt, V, E, H, NL))
     return sample_fwd_fused<TA>(c, P, S, st, noise_u, seed, temperature, pretrain, out, ids, opt, stream);
   GIC_CHECK_ARG(st->logits && st->gpre, "decoder_sample_fwd: the unfused path needs state->logits and state->gpre");
   const bool keep = !(opt && opt->no_state);
@@ -492,12 +455,16 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
       if (M > M_prev) {
         for (int l = 0; l < NL; ++l) {
           const long rowbytes = c.ldx(l) * (long)c.asz();
-          const long work = (long)(M - M_prev) * (rowbytes / 16);
-          hipLaunchKernelGGL(rollout_join_kernel, dim3((unsigned)(work + 255) / 256 > 2048 ? 2048 : (unsigned)((work + 255) / 256)), dim3(256), 0, stream,
-                             (const unsigned char*)opt->resume_from->xh[l] + (size_t)t * opt->resume_B * rowbytes,
-                             (unsigned char*)st->xh[l] + (size_t)t * B * rowbytes, rowbytes,
-                             (const float*)(opt->resume_from->c[l] + (long)t * opt->resume_B * H), st->c[l] + (long)t * B * H, H,
-                             (long)M_prev, (long)M, opt->resume_B);
+          const int pb = rowbytes % 16 == 0 ? 16 : (rowbytes % 4 == 0 ? 4 : 2);      // rowbytes is a multiple of the element size
+          const long work = (long)(M - M_prev) * (rowbytes / pb);
+          const dim3 jgrid((unsigned)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256));
+          const unsigned char* jsrc = (const unsigned char*)opt->resume_from->xh[l] + (size_t)t * opt->resume_B * rowbytes;
+          unsigned char* jdst = (unsigned char*)st->xh[l] + (size_t)t * B * rowbytes;
+          const float* jsc = (const float*)(opt->resume_from->c[l] + (long)t * opt->resume_B * H);
+          float* jdc = st->c[l] + (long)t * B * H;
+          if (pb == 16) hipLaunchKernelGGL(rollout_join_kernel<16>, jgrid, dim3(256), 0, stream, jsrc, jdst, rowbytes, jsc, jdc, H, (long)M_prev, (long)M, opt->resume_B);
+          else if (pb == 4) hipLaunchKernelGGL(rollout_join_kernel<4>, jgrid, dim3(256), 0, stream, jsrc, jdst, rowbytes, jsc, jdc, H, (long)M_prev, (long)M, opt->resume_B);
+          else hipLaunchKernelGGL(rollout_join_kernel<2>, jgrid, dim3(256), 0, stream, jsrc, jdst, rowbytes, jsc, jdc, H, (long)M_prev, (long)M, opt->resume_B);
           GIC_CHECK_LAUNCH("rollout_join");
         }
       }
@@ -564,7 +531,7 @@ int sample_bwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
                                      G->w_out, G->b_out, stream));
   if (!(phases & GIC_DECODER_BWD_RECURRENT)) return GIC_OK;
   // 3. BPTT
-  bool fused = decoder_step_supported(c.dt, 4, 8, H, NL) && H % 2 == 0 && B <= 512;
+  bool fused = decoder_step_supported(c.dt, 4, 8, H, NL) && H % 2 == 0 && B <= decoder_step_max_rows();
   for (int l = 0; l < NL; ++l) fused = fused && S->wcat_t[l] != nullptr;
   for (int l = 0; l < NL; ++l) GIC_PROPAGATE(fill_zero(ws->dc[l], (size_t)B * H * sizeof(float), stream));
   if (fused) {
@@ -837,6 +804,14 @@ int gic_decoder_forward_tf(const gic_decoder_dims* dims, const gic_decoder_param
 }
 
 void gic_debug_decoder_step(int v) { decoder_step_debug(v); }
+
+int gic_decoder_fused_rollout_rows(const gic_decoder_dims* dims, int32_t* out) {
+  Ctx c;
+  GIC_PROPAGATE(check_dims(dims, c));
+  GIC_CHECK_ARG(out, "decoder_fused_rollout_rows: null out");
+  *out = decoder_step_supported(c.dt, c.V, c.E, c.H, c.NL) ? decoder_step_max_rows() : 0;
+  return GIC_OK;
+}
 
 int gic_decoder_state_bytes(const gic_decoder_dims* dims, uint64_t* out) {
   Ctx c;

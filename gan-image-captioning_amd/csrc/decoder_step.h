@@ -7,8 +7,10 @@
 //               and the UNNORMALISED probabilities e = exp(y - tile max)
 // and one launch after the last step (sample_finish): global max / sum per (caption, step) from the partials, token ids,
 // probabilities p = e * exp(tile max - global max) / global sum.
-// A grid-wide barrier inside one persistent launch costs 4.1-4.8 us on this chip (MI355X_MICROARCH.md price list, barrier-xcd)
-// against 1.45 us for a dependent kernel boundary, so the seams stay kernel boundaries and each kernel is sized to its floor:
+// A grid-wide barrier inside one persistent launch costs 4.1-4.8 us on this chip (MI355X_MICROARCH.md price list, barrier-xcd; the
+// single-launch roll-out built in round 2 measured ~19 us per barrier with the step's dirty lines to write back: 943 us per roll-out
+// against 423 us; removed in round 3) against 1.45 us for a dependent kernel boundary, so the seams stay kernel
+// boundaries and each kernel is sized to its floor:
 // the 14 MB of decoder weights stay resident in the eight XCD L2s (4 MB each) between steps because the block -> weight-slice
 // map is the same in every step.
 #pragma once
@@ -64,7 +66,6 @@ struct SampleFinishArgs {
   int64_t* ids = nullptr;                    // [B, L]
   const int64_t* force_ids = nullptr; const int32_t* force_len = nullptr;
   const float* embed = nullptr; void* xh0 = nullptr; long ldx0 = 0;     // x rows of XH_0 slots 1..L-1 (for the weight gradient) or null
-  const unsigned int* err = nullptr;         // error flag of the persistent roll-out kernel (non-zero: ids = -1, probabilities = NaN) or null
 };
 
 // One BPTT step of one layer (reverse of lstm_step): dh = dh_above + dgates_{t+1} W_hh [+ dgates^{l+1}_t W_ih^{l+1}], then the
@@ -85,32 +86,11 @@ struct LstmBwdStepArgs {
 };
 int lstm_bwd_step(const LstmBwdStepArgs& a, int dtype, hipStream_t stream);
 
-// The whole single-layer roll-out as ONE persistent launch: per step the lstm_step body, a grid barrier, the vocab_step body, a grid
-// barrier (sample_finish stays its own launch).  `l0` / `v0` are the arguments of step 0; step t advances their per-step pointers by
-// the strides below.  Inside the train step the 41 launches of the two-launch form each wait for 128-157 free CUs beside the
-// look-ahead trunk pass (measured: the roll-out takes 0.48 ms with the chip to itself and 1.35 ms beside the trunk pass); the
-// persistent grid acquires its CUs once.
-struct RolloutArgs {
-  LstmStepArgs l0;
-  VocabStepArgs v0;
-  int L = 0;
-  long xh_step = 0;          // bytes between time slots of XH_0
-  long c_step = 0;           // floats between time slots of c
-  long gates_step = 0;       // floats between steps of the saved gates (0 if null)
-  long hout_step = 0;        // bytes between steps of hout[b, t, :] (0 if null)
-  long out_step = 0;         // bytes between steps of out[b, t, :] (0 if null)
-  long part_step = 0;        // floats between steps of part_m / part_s
-  long u_step = 0;           // floats between steps of the explicit uniforms (0 if null)
-  const unsigned long long* rowkey0 = nullptr;   // [L][B] argmax keys (= v0.rowkey)
-  unsigned int* sync = nullptr;                  // [2] zeroed by the caller: barrier counter, error flag
-  int grid_l = 0, grid_lx = 0, grid_v = 0, grid_vx = 0;   // workgroups of the lstm / vocab phase and their x extent
-};
-bool rollout_persistent_supported(int dtype, int B, int V, int E, int H, int NL);
-int rollout_persistent(const RolloutArgs& r, int dtype, hipStream_t stream);
-
 // true if the fused kernels take these shapes (else the caller uses the generic GEMM + pointwise launches)
 bool decoder_step_supported(int dtype, int V, int E, int H, int NL);
-size_t decoder_step_part_floats(int B, int L, int V);       // floats in the partials scratch: [2][L][B][nblk] floats + [L][B] 64-bit keys + 2 sync words
+// most batch rows the fused roll-out takes (GIC_FUSED_ROLLOUT_MAX_ROWS, default 512): beyond it the per-step products are large GEMMs
+int decoder_step_max_rows();
+size_t decoder_step_part_floats(int B, int L, int V);       // floats in the partials scratch: [2][L][B][nblk] floats + [L][B] 64-bit keys + 2 reserved words
 void decoder_step_debug(int v);                             // phase-ablation knob of tools/rollout_bench.py (0 = normal)
 int lstm_step(const LstmStepArgs& a, int dtype, hipStream_t stream);
 int vocab_step(const VocabStepArgs& a, int dtype, hipStream_t stream);

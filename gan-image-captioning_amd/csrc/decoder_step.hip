@@ -134,7 +134,7 @@ template <> __device__ __forceinline__ u32x4 pack_f32_chunk<bf16_t>(const f32x4&
 // the texture addresser (measured 3x slower).  The 16 weight rows of the block are few enough to go straight to fragments.
 // The 8 waves split the k-steps of a chunk; their partial sums meet in LDS (the staging area, reused) and 256 threads apply the
 // cell nonlinearities.
-// (device body: workgroup (bx, by) of the launch grid; shared with the persistent roll-out kernel, which calls it once per step)
+// (device body: workgroup (bx, by) of the launch grid)
 template <typename TA>
 __device__ __forceinline__ void lstm_step_body(const LstmStepArgs& a, const int KC, const int bx, const int by, unsigned char* ls_smem, int* ids_s) {
   constexpr int SZ = sizeof(TA), VE = 16 / SZ;
@@ -568,73 +568,6 @@ __global__ __launch_bounds__(512) void vocab_step_kernel(const VocabStepArgs a, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Persistent roll-out: grid barrier = one agent-scope atomic add per workgroup on a monotonic counter + a bounded poll (a workgroup
-// that waits longer than ~2 s, or sees the error flag, sets the flag and leaves: the launch always drains; sample_finish turns the
-// flag into NaNs).  Release / acquire fences around it make the step's stores (h_t, partials, argmax keys) visible across XCDs.
-__device__ __forceinline__ bool grid_sync(unsigned int* sync, const unsigned int target) {
-  __shared__ int ok_s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();                                     // release: write back this XCD's dirty lines before the arrival is counted
-    __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int ok = 1;
-    unsigned int spins = 0;
-    while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {     // (one acquire fence after the loop)
-      __builtin_amdgcn_s_sleep(2);
-      if ((++spins & 63u) == 0 && (spins > (1u << 22) || __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-        __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
-    }
-    __threadfence();
-    ok_s = ok;
-  }
-  __syncthreads();
-  return ok_s != 0;
-}
-
-template <typename TA, bool FAST>
-__global__ __launch_bounds__(512) void rollout_persistent_kernel(const RolloutArgs r, const int KCL, const int KCV) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char rp_smem[];
-  __shared__ int ids_s[kStepRows];
-  const int bid = blockIdx.x, G = gridDim.x;
-  unsigned int phase = 0;
-  for (int t = 0; t < r.L; ++t) {
-    if (bid < r.grid_l) {
-      LstmStepArgs a = r.l0;
-      a.xh_t = (const unsigned char*)r.l0.xh_t + t * r.xh_step;
-      a.xh_next = (unsigned char*)r.l0.xh_next + t * r.xh_step;
-      a.c_prev = r.l0.c_prev + t * r.c_step;
-      a.c_new = r.l0.c_new + t * r.c_step;
-      if (r.l0.gates) a.gates = r.l0.gates + t * r.gates_step;
-      if (r.l0.h_out) a.h_out = (unsigned char*)r.l0.h_out + t * r.hout_step;
-      if (t > 0) {                                       // x_t = embed[token of step t-1] (forced trajectory, else the argmax key)
-        a.gather = 1;
-        a.rowkey = r.rowkey0 + (long)(t - 1) * r.l0.B;
-        a.tprev = t - 1;
-      } else {
-        a.gather = 0; a.rowkey = nullptr; a.force_ids = nullptr;
-      }
-      lstm_step_body<TA>(a, KCL, bid % r.grid_lx, bid / r.grid_lx, rp_smem, ids_s);
-    }
-    if (!grid_sync(r.sync, ++phase * (unsigned int)G)) return;
-    if (bid < r.grid_v) {
-      VocabStepArgs v = r.v0;
-      v.h = (const unsigned char*)r.v0.h + t * r.xh_step;
-      if (r.v0.u) v.u = r.v0.u + t * r.u_step;
-      v.rng_stream = r.v0.rng_stream + (uint64_t)t;
-      if (r.v0.out) v.out = (unsigned char*)r.v0.out + t * r.out_step;
-      v.part_m = r.v0.part_m + t * r.part_step;
-      v.part_s = r.v0.part_s + t * r.part_step;
-      v.rowkey = r.v0.rowkey + (long)t * r.v0.B;
-      vocab_step_body<TA, FAST>(v, KCV, bid % r.grid_vx, bid / r.grid_vx, rp_smem);
-    }
-    if (t + 1 < r.L && !grid_sync(r.sync, ++phase * (unsigned int)G)) return;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // sample_finish: one block per (step, caption).  Global max / sum from the tile partials; token id (argmax, or the forced one);
 // p = e * exp(tile max - global max) / global sum (generator.py:69: softmax over the whole vocabulary); the embedding row of the
 // token into the next step's x slot of XH_0 (operand of the LSTM weight gradient).
@@ -649,7 +582,7 @@ __global__ __launch_bounds__(256) void sample_finish_kernel(const SampleFinishAr
   int id = row_key_index(a.rowkey[(long)t * a.B + b]);
   if (a.force_ids && (!a.force_len || t < a.force_len[b])) id = (int)a.force_ids[(long)b * a.L + t];
   id = id < 0 ? 0 : (id >= a.V ? a.V - 1 : id);
-  if (tid == 0) a.ids[(long)b * a.L + t] = (a.err && *a.err != 0u) ? (int64_t)-1 : (int64_t)id;      // -1: the roll-out failed (see below)
+  if (tid == 0) a.ids[(long)b * a.L + t] = (int64_t)id;
   if (a.xh0 && t + 1 < a.L) {
     TA* dst = (TA*)a.xh0 + ((long)(t + 1) * a.B + b) * a.ldx0;
     for (int e = tid; e < a.E; e += 256) dst[e] = from_f32<TA>(a.embed[(long)id * a.E + e]);
@@ -661,8 +594,7 @@ __global__ __launch_bounds__(256) void sample_finish_kernel(const SampleFinishAr
   float s = 0.f;
   for (int j = tid; j < a.nblk; j += 256) s += a.part_s[po + j] * expf(pm[j] - bm);
   s = block_sum(s, red);
-  // a persistent roll-out whose grid barrier gave up (error flag) must not pass for a result: NaN probabilities
-  const float inv = (a.err && *a.err != 0u) ? __builtin_nanf("") : 1.f / s;
+  const float inv = 1.f / s;
   for (int j = tid; j < a.nblk; j += 256) scale_s[j] = expf(pm[j] - bm) * inv;
   __syncthreads();
   TA* row = (TA*)a.out + ((long)b * a.L + t) * a.V;
@@ -745,19 +677,14 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(const LstmBwdStepArg
   }
 }
 
-static int g_step_dbg = 0;      // gic_debug_decoder_step: 1 | 2 | 4 load-ablation bits of tools/rollout_bench.py, 8 = persistent roll-out kernel
+static int g_step_dbg = 0;      // gic_debug_decoder_step: 1 | 2 | 4 load-ablation bits of tools/rollout_bench.py
 
-// dynamic LDS beyond 64 KB must be granted per kernel; `granted` = what the caller's kernel already has (one static per kernel)
+// dynamic LDS beyond 64 KB: per kernel and per device (common.h grant_lds)
 template <typename K>
-int allow_lds(K kernel, size_t bytes, size_t& granted) {
-  if (bytes <= granted) return GIC_OK;
-  if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-    (void)hipGetLastError();
-    set_last_error("decoder step kernel: cannot reserve %zu bytes of LDS", bytes);
-    return GIC_ERR_LAUNCH;
-  }
-  granted = bytes;
-  return GIC_OK;
+int allow_lds(K kernel, size_t bytes, LdsGrant& g) {
+  if (grant_lds(kernel, bytes, g)) return GIC_OK;
+  set_last_error("decoder step kernel: cannot reserve %zu bytes of LDS", bytes);
+  return GIC_ERR_LAUNCH;
 }
 
 // K chunk (elements) staged per pass: 1 KiB of a row in vocab_step (two tiles), 2 KiB in lstm_step (one tile); multiples of 32
@@ -785,42 +712,15 @@ bool decoder_step_supported(int dtype, int V, int E, int H, int NL) {
 }
 
 size_t decoder_step_part_floats(int B, int L, int V) {
-  // + the 64-bit row keys (8-byte aligned) + the persistent kernel's two sync words behind them
+  // + the 64-bit row keys (8-byte aligned) + two reserved 32-bit words behind them (ABI v2 sizing, unused)
   return (size_t)2 * L * B * ((V + kVocabTile - 1) / kVocabTile) + (size_t)2 * L * B + 4;
 }
 
 void decoder_step_debug(int v) { g_step_dbg = v; }
 
-bool rollout_persistent_supported(int dtype, int B, int V, int E, int H, int NL) {
-  // OFF by default: measured 945 us per roll-out alone and 3.64 ms per train step against 422 us / 2.85 ms for two launches per step
-  // (a grid barrier = L2 write-back + L1 invalidate + a cross-XCD counter hop costs ~19 us here, a kernel boundary 2.2 us).
-  // GIC_PERSISTENT_ROLLOUT=1 or gic_debug_decoder_step(8) selects it (tools/rollout_bench.py, tests).
-  static const bool on = [] { const char* e = getenv("GIC_PERSISTENT_ROLLOUT"); return e ? atoi(e) != 0 : false; }();
-  if ((!on && !(g_step_dbg & 8)) || NL != 1 || !decoder_step_supported(dtype, V, E, H, NL)) return false;
-  const int by = cdiv(B, kStepRows);
-  const int gl = cdiv(H, kUnitsPerBlock) * by, gv = cdiv(V, kVocabTile) * by;
-  // every workgroup must be resident at once (one per CU: the staging areas fill most of a CU's LDS); leave CUs to the other streams
-  return gl <= 200 && gv <= 200;
-}
-
-int rollout_persistent(const RolloutArgs& r0, int dtype, hipStream_t stream) {
-  RolloutArgs r = r0;
-  r.l0.dbg = r.v0.dbg = g_step_dbg;
-  GIC_CHECK_ARG(r.sync && r.L > 0 && r.grid_l > 0 && r.grid_v > 0 && r.grid_lx > 0 && r.grid_vx > 0, "rollout_persistent: bad arguments");
-  const size_t ll = lstm_lds_bytes(dtype, (int)r.l0.ldx), lv = vocab_lds_bytes(dtype, r.v0.H);
-  const size_t lds = ll > lv ? ll : lv;
-  const int KCL = lstm_chunk(dtype, (int)r.l0.ldx), KCV = vocab_chunk(dtype, r.v0.H);
-  const dim3 grid((unsigned)(r.grid_l > r.grid_v ? r.grid_l : r.grid_v));
-  static size_t granted_f32 = 64 * 1024, granted_bf16 = 64 * 1024;
-  if (dtype == DT_F32) {
-    GIC_PROPAGATE(allow_lds(rollout_persistent_kernel<float, false>, lds, granted_f32));
-    hipLaunchKernelGGL((rollout_persistent_kernel<float, false>), grid, dim3(512), lds, stream, r, KCL, KCV);
-  } else {
-    GIC_PROPAGATE(allow_lds(rollout_persistent_kernel<bf16_t, true>, lds, granted_bf16));
-    hipLaunchKernelGGL((rollout_persistent_kernel<bf16_t, true>), grid, dim3(512), lds, stream, r, KCL, KCV);
-  }
-  GIC_CHECK_LAUNCH("rollout_persistent");
-  return GIC_OK;
+int decoder_step_max_rows() {
+  static const int rows = [] { const char* e = getenv("GIC_FUSED_ROLLOUT_MAX_ROWS"); return e ? atoi(e) : 512; }();
+  return rows;
 }
 
 int lstm_step(const LstmStepArgs& a, int dtype, hipStream_t stream) {
@@ -833,12 +733,13 @@ int lstm_step(const LstmStepArgs& a, int dtype, hipStream_t stream) {
   b.dbg = g_step_dbg;
   const int KC = lstm_chunk(dtype, (int)a.ldx);
   const size_t lds = lstm_lds_bytes(dtype, (int)a.ldx);
-  static size_t granted_f32 = 64 * 1024, granted_bf16 = 64 * 1024;
   if (dtype == DT_F32) {
-    GIC_PROPAGATE(allow_lds(lstm_step_kernel<float>, lds, granted_f32));
+    static LdsGrant g32;
+    GIC_PROPAGATE(allow_lds(lstm_step_kernel<float>, lds, g32));
     hipLaunchKernelGGL((lstm_step_kernel<float>), grid, dim3(512), lds, stream, b, KC);
   } else {
-    GIC_PROPAGATE(allow_lds(lstm_step_kernel<bf16_t>, lds, granted_bf16));
+    static LdsGrant g16;
+    GIC_PROPAGATE(allow_lds(lstm_step_kernel<bf16_t>, lds, g16));
     hipLaunchKernelGGL((lstm_step_kernel<bf16_t>), grid, dim3(512), lds, stream, b, KC);
   }
   GIC_CHECK_LAUNCH("lstm_step");
@@ -865,12 +766,13 @@ int vocab_step(const VocabStepArgs& a0, int dtype, hipStream_t stream) {
   const size_t lds = vocab_lds_bytes(dtype, a.H);
   const int KC = vocab_chunk(dtype, a.H);
   const dim3 grid((unsigned)a.nblk, (unsigned)cdiv(a.B, kStepRows));
-  static size_t granted_f32 = 64 * 1024, granted_bf16 = 64 * 1024;
   if (dtype == DT_F32) {
-    GIC_PROPAGATE(allow_lds(vocab_step_kernel<float, false>, lds, granted_f32));
+    static LdsGrant g32;
+    GIC_PROPAGATE(allow_lds(vocab_step_kernel<float, false>, lds, g32));
     hipLaunchKernelGGL((vocab_step_kernel<float, false>), grid, dim3(512), lds, stream, a, KC);
   } else {
-    GIC_PROPAGATE(allow_lds(vocab_step_kernel<bf16_t, true>, lds, granted_bf16));
+    static LdsGrant g16;
+    GIC_PROPAGATE(allow_lds(vocab_step_kernel<bf16_t, true>, lds, g16));
     hipLaunchKernelGGL((vocab_step_kernel<bf16_t, true>), grid, dim3(512), lds, stream, a, KC);
   }
   GIC_CHECK_LAUNCH("vocab_step");

@@ -93,9 +93,10 @@ class TrunkPlan:
         self._graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
         self._warm: set = set()
         self.fuse_in = not os.environ.get("GIC_NO_FUSED_BN_IN")
-        # block outputs formed on load by the next conv1 (gic_conv1x1_res_in): opt-in.  Measured at cfg2 it takes 0.31 ms of bn_act out of
-        # the step and adds 0.20 ms to seven conv1 launches (step 3.18 -> 3.14 ms, within run-to-run noise): see DESIGN.md section 4
-        self.fuse_res = os.environ.get("GIC_FUSED_RES_IN", "1") != "0"     # block outputs formed on load by the next conv1 (large grids)
+        # block outputs formed on load by the next conv1 (gic_conv1x1_res_in): ON by default for the large grids (>= res_min_rows rows,
+        # single-channel-tile conv1s); GIC_FUSED_RES_IN=0 restores the separate bn_act pass.  Measured at cfg2 with the parallel replica
+        # folds: 3.01 -> 2.92 ms per step; parity: test_block_output_formed_on_load_equals_the_separate_pass
+        self.fuse_res = os.environ.get("GIC_FUSED_RES_IN", "1") != "0"
         self.res_min_rows = int(os.environ.get("GIC_RES_IN_MIN_ROWS", "50000"))
         self.res_max_cout = int(os.environ.get("GIC_RES_IN_MAX_COUT", "128"))
         self._nrep = {}
@@ -316,11 +317,13 @@ class TrunkPlan:
             self._warm.add(key)                # first call: eager (lazy code-object loads are not capturable)
             self._run_trunk(b, N, S, training)
         else:
-            self._graphs.clear()               # at most one live graph per plan: stale pointers never replay
+            self._graphs.clear()               # at most one live graph per plan: stale pointers never replay (dies here, outside capture)
             g = torch.cuda.CUDAGraph()
             try:
+                # capture_guard: the collector runs before the region and not inside it (engine.capture_guard; _run_trunk allocates
+                # tuples / ctypes structs per launch, enough to trigger a generational collection mid-capture).
                 # thread_local: other threads of the process (RCCL's watchdog polls events) may keep calling HIP during capture
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with engine.capture_guard(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._run_trunk(b, N, S, training)
             except Exception as exc:           # capture refused: keep training with eager launches (same kernels, same results)
                 import warnings

@@ -25,6 +25,29 @@ def bump_param_epoch() -> None:
     _param_epoch += 1
 
 
+class capture_guard:
+    """Bracket for a hipGraph capture region: no cyclic garbage collection may run inside it.
+
+    A generational collection that fires between two captured launches finalises whatever HIP-owning garbage the process has
+    accumulated (stale ``CUDAGraph``s with their private pools, streams, events of dropped plans): a destructor that frees device
+    memory or destroys a graph while a capture is open throws inside a C++ destructor -> ``std::terminate`` (the rc=134 abort of
+    round 2).  torch >= 2.6 no longer collects before a capture (``force_cudagraph_gc`` is off), so this
+    does: collect BEFORE the region (the garbage dies outside it), disable the collector inside, restore it afterwards."""
+
+    def __enter__(self):
+        import gc
+        self._gc = gc
+        self._was_enabled = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        if self._was_enabled:
+            self._gc.enable()
+        return False
+
+
 def parse_dtype(x) -> int:
     if isinstance(x, int):
         return x
@@ -236,22 +259,30 @@ class DecoderEngine:
         }
 
     def part_floats(self, B: int, Lc: int) -> int:
-        """Floats of the fused step kernels' scratch: [2][L][B][ceil(V/64)] tile partials + [L][B] 64-bit argmax keys + the persistent
-        roll-out kernel's two sync words (gicap.h; = gic_decoder_state_bytes' figure)."""
+        """Floats of the fused step kernels' scratch: [2][L][B][ceil(V/64)] tile partials + [L][B] 64-bit argmax keys + two reserved
+        words (gicap.h; = gic_decoder_state_bytes' figure)."""
         return 2 * Lc * B * ((self.V + 63) // 64) + 2 * Lc * B + 4
+
+    def fused_rollout_rows(self) -> int:
+        """Largest batch the fused step kernels take for this decoder's shapes; 0: they decline them (gic_decoder_fused_rollout_rows:
+        the library's own path selection, so buffer planning here cannot disagree with it)."""
+        out = C.c_int32(0)
+        L.check(L.load().gic_decoder_fused_rollout_rows(C.byref(self.dims(1, 1)), C.byref(out)), "gic_decoder_fused_rollout_rows")
+        return int(out.value)
 
     def alloc_rollout_state(self, B: int, Lc: int, dev) -> Dict[str, object]:
         """State of an inference roll-out (``no_state``): recurrent buffers only, nothing saved for a backward pass."""
         f32 = torch.float32
+        fused = B <= self.fused_rollout_rows()
         return {
             "xh": [torch.empty(Lc + 1, B, self.ldx(l), device=dev, dtype=self.act) for l in range(self.NL)],
             "gates": [None] * self.NL,
             "c": [torch.empty(Lc + 1, B, self.H, device=dev, dtype=f32) for _ in range(self.NL)],
             "hout": None,
-            # beyond the fused kernels' row limit the roll-out runs as generic products: their scratch
-            "logits": torch.empty(B, self.V, device=dev, dtype=f32) if B > 512 else None,
-            "gpre": torch.empty(B, 4 * self.H, device=dev, dtype=f32) if B > 512 else None,
-            "part": torch.empty(self.part_floats(B, Lc), device=dev, dtype=f32) if B <= 512 else None,
+            # where the fused step kernels decline (row limit, V % 4, E % 8, H % 8) the roll-out runs as generic products: their scratch
+            "logits": None if fused else torch.empty(B, self.V, device=dev, dtype=f32),
+            "gpre": None if fused else torch.empty(B, 4 * self.H, device=dev, dtype=f32),
+            "part": torch.empty(self.part_floats(B, Lc), device=dev, dtype=f32) if fused else None,
         }
 
     def _state_struct(self, st) -> L.DecoderState:
@@ -331,8 +362,9 @@ class DecoderEngine:
             opts.no_state = int(bool(ids_only))
         if resume is not None:
             src_state, src_B, active = resume
-            if len(active) != Lc or force_ids is None or force_len is None or not ids_only or B <= 512:
-                raise ValueError("resumed roll-outs: active_rows per step, force_ids, force_len, ids_only and more than 512 rows")
+            if len(active) != Lc or force_ids is None or force_len is None or not ids_only or st.get("logits") is None:
+                raise ValueError("resumed roll-outs: active_rows per step, force_ids, force_len, ids_only and a state with the generic "
+                                 "products' scratch (more rows than the fused step kernels take)")
             src_struct = self._state_struct(src_state)
             act = _arr(C.c_int32, Lc, [int(v) for v in active])
             opts.resume_from = C.cast(C.pointer(src_struct), C.c_void_p)

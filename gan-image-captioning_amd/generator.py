@@ -219,6 +219,10 @@ class AttnDecoder(nn.Module):
         super().__init__()
         if args.gen_num_layers != 1:
             raise ValueError("--decoder attention supports one LSTM layer")
+        if args.vocab_size % 4 or args.gen_embed_dim % 8 or args.gen_hidden_dim % 8 or feat_c % 8 or int(getattr(args, "attn_dim", 512)) % 8:
+            # gic_attn_* (attention.hip check_attn_dims) would refuse these at the first step: say so at construction
+            raise ValueError("--decoder attention needs vocab_size % 4 == 0 and gen_embed_dim / gen_hidden_dim / attn_dim % 8 == 0 "
+                             f"(got V={args.vocab_size}, E={args.gen_embed_dim}, H={args.gen_hidden_dim}); main.py pads the vocabulary")
         self.embed = Embedding(args.vocab_size, args.gen_embed_dim)
         self.lstm = _LSTMParams(args.gen_embed_dim + feat_c, args.gen_hidden_dim, 1)
         self.linear = _LinearParams(args.gen_hidden_dim, args.vocab_size)

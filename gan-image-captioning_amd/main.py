@@ -36,6 +36,10 @@ def main(argv=None):
         train = COCO_data(args.data_dir + "/dataset_coco.json", args.data_dir, "train", args.image_size,
                           args.captions_per_image, dataset_percent=args.dataset_percent)
         args.vocab_size = train.vocab_size                                       # main.py:38
+        if getattr(args, "decoder", "lstm") == "attention" and args.vocab_size % 4:
+            # the attention kernels (no reference counterpart) move vocabulary rows in 16-byte pieces: V is rounded up to a multiple
+            # of 4; the extra classes never occur in the data (the LSTM decoder and the discriminator take any V)
+            args.vocab_size += 4 - args.vocab_size % 4
         val = COCO_data(args.data_dir + "/dataset_coco.json", args.data_dir, "val", args.image_size, args.captions_per_image,
                         vocab_dicts=(train.word_to_index, train.index_to_word), dataset_percent=args.dataset_percent)
     inst = GANInstructor(args, train, val)

@@ -73,14 +73,17 @@ class GradReducer:
     collective.  CPU tensors (gloo rehearsal): synchronous.
     """
 
-    def __init__(self, info: DistInfo):
+    def __init__(self, info: DistInfo, force: bool = False):
+        """``force``: run the collectives even with world_size 1 (a 1-rank RCCL communicator: the identity, bit for bit) -- lets a
+        one-GPU box execute the device branch and the fused step's reducer schedule (tests/test_gpu_dp.py)."""
         self.info = info
+        self.force = bool(force)
         self._side: Optional[torch.cuda.Stream] = None
         self._pending: List[torch.cuda.Event] = []
 
     def start(self, flat: torch.Tensor):
         """Returns the collective's completion event (None when it ran synchronously) for ``wait``."""
-        if self.info.world_size <= 1:
+        if self.info.world_size <= 1 and not self.force:
             return None
         if not flat.is_cuda or dist.get_backend() == "gloo":      # gloo has no AVG; on device tensors it stages through the host
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)

@@ -81,7 +81,7 @@ class SeqGANStep:
             force = Y.repeat(reps, 1)
             flen = torch.arange(1, L, device=dev, dtype=torch.int32).repeat_interleave(N * B)
             resume = None
-            if reps * B > 512:
+            if reps * B > dec.fused_rollout_rows():
                 # generic-product path: a roll-out does not recompute its prefix, it starts at step t from pass 4a's state (rows are
                 # sorted by prefix length: at step t the first t*N*B rows exist) -- half the row-steps of the full batch
                 resume = (st, B, [min(t, L - 1) * N * B for t in range(L)])

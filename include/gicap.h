@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GIC_ABI_VERSION 2
+#define GIC_ABI_VERSION 3
 #define GIC_MAX_LAYERS 4
 #define GIC_MAX_CONVS 8
 
@@ -110,8 +110,8 @@ typedef struct gic_decoder_state {
   float* logits;                         /* scratch [B, V] */
   float* gpre;                           /* scratch [B, 4H] */
   float* part;                           /* scratch of the fused step kernels: [2][L][B][ceil(V/64)] per-tile softmax partials (max, sum of
-                                            exp) + [L][B] 64-bit argmax keys + two 32-bit words of the opt-in persistent roll-out kernel (barrier counter, error
-                                            flag); size from gic_decoder_state_bytes, 8-byte aligned.
+                                            exp) + [L][B] 64-bit argmax keys + two reserved 32-bit words; size from gic_decoder_state_bytes,
+                                            8-byte aligned.
                                             NULL selects the unfused launches. */
 } gic_decoder_state;
 
@@ -162,6 +162,13 @@ int gic_decoder_sample_fwd(const gic_decoder_dims* dims, const gic_decoder_param
 
 /* Tools only (tools/rollout_bench.py): phase-ablation mask of the fused step kernels; 0 = normal operation. */
 void gic_debug_decoder_step(int mask);
+
+/* Which roll-out path gic_decoder_sample_fwd takes for `dims` (host-only, no GPU needed): *out_rows = the largest batch B the fused
+ * step kernels take for these V / E / H / NL (GIC_FUSED_ROLLOUT_MAX_ROWS, default 512), or 0 when they decline the shapes
+ * (V % 4, E % 8, H % 8, GIC_NO_FUSED_ROLLOUT).  A call with B beyond that, with state->part == NULL or with opts->resume_from runs
+ * the generic products and NEEDS state->logits and state->gpre; a caller that sizes its buffers by this query never trips that check
+ * (Decoder.sample, src/generator.py:55-81, takes any vocabulary / embedding size). */
+int gic_decoder_fused_rollout_rows(const gic_decoder_dims* dims, int32_t* out_rows);
 
 /* Decoder.forward, the teacher-forced decode (src/generator.py:39-53; forward only: the reference's training never calls it).
  * dims->L = T = caption length + 1 time steps: step 0 is fed `features`, step t > 0 embed(caps[b, t-1]) (caps int64 [B, T-1]).

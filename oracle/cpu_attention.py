@@ -79,3 +79,28 @@ def attn_decoder_sample(gp: O.Params, features: Tensor, fmap: Tensor, max_captio
         alphas.append(alpha)
         x = gp[f"{prefix}embed.weight"][idx.detach()]
     return torch.stack(outs, 1), torch.stack(ids, 1), torch.stack(alphas, 1)
+
+
+def attn_adv_step(gp: O.Params, dp: O.Params, captions: Tensor, us: Sequence[Tensor], masks: Optional[Sequence[Tensor]], temperature: float,
+                  trunk_feat: Tensor, fmap: Tensor, loss_type: str = "standard", num_rep: int = 64,
+                  force_ids: Optional[Tensor] = None) -> dict:
+    """The adversarial G+D step of oracle/cpu_step.adv_step (body of reference src/training.py:144-169 in the fixed order) with the
+    attention decoder as the sampler: features = encoder head(trunk_feat) -> attn_decoder_sample over ``fmap`` [B,P,C] -> the three
+    discriminator passes -> losses -> raw gradients of D (from d_loss) and of G's trainable tensors (decoder incl. attention, encoder
+    head; from g_loss).  No optimizer (the composed test compares gradients).  ``force_ids``: as in cpu_step.decoder_sample."""
+    vocab = gp["decoder.linear.weight"].shape[0]
+    g_names = [k for k in gp if k.startswith(("decoder.", "encoder.linear.", "encoder.bn."))]
+    g_leaf = {k: gp[k].detach().clone().requires_grad_(True) for k in g_names}
+    d_leaf = {k: v.detach().clone().requires_grad_(True) for k, v in dp.items()}
+    feats = O.encoder_head(g_leaf, trunk_feat)
+    gen, ids, _ = attn_decoder_sample(g_leaf, feats, fmap, captions.shape[1], temperature, us, force_ids=force_ids)
+    real = torch.nn.functional.one_hot(captions, vocab).float()
+    m = masks if masks is not None else (None, None, None)
+    d_real = O.disc_forward(d_leaf, real, m[0], num_rep)
+    d_fake = O.disc_forward(d_leaf, gen.detach(), m[1], num_rep)
+    g_out = O.disc_forward(d_leaf, gen, m[2], num_rep)
+    g_loss, d_loss = O.get_losses(d_real, d_fake, g_out, loss_type)
+    d_grads = dict(zip(d_leaf, torch.autograd.grad(d_loss, list(d_leaf.values()), retain_graph=True)))
+    g_t = torch.autograd.grad(g_loss, list(g_leaf.values()), allow_unused=True)
+    return {"probs": gen.detach(), "ids": ids, "g_loss": float(g_loss.detach()), "d_loss": float(d_loss.detach()),
+            "d_grads_raw": d_grads, "g_grads_raw": {k: g for k, g in zip(g_leaf, g_t) if g is not None}}

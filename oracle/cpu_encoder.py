@@ -56,14 +56,24 @@ def bn_name(conv_name: str) -> str:
     return conv_name.replace("conv", "bn")
 
 
-def make_trunk_params(arch: str, gen: torch.Generator, prefix: str = "encoder.resnet.") -> Dict[str, torch.Tensor]:
-    """U(-0.05, 0.05) for conv weights AND BatchNorm affine parameters (Generator.init_params, generator.py:116-123)."""
+def make_trunk_params(arch: str, gen: torch.Generator, prefix: str = "encoder.resnet.", init: str = "uniform") -> Dict[str, torch.Tensor]:
+    """init="uniform": U(-0.05, 0.05) for conv weights AND BatchNorm affine parameters (Generator.init_params, generator.py:116-123:
+    what the reference trains from).  init="kaiming": the published ResNet initialisation (He et al. 2015: N(0, 2 / fan_out) conv
+    weights, gamma = 1, beta = 0) -- what a trunk looks like before init_params overwrites it, and the shape of any trained trunk's
+    statistics; used to show which part of the bf16 error budget is an artefact of the degenerate uniform init."""
     p: Dict[str, torch.Tensor] = {}
     for name, cin, cout, k, _s, _p in layer_specs(arch):
-        p[prefix + name + ".weight"] = torch.empty(cout, cin, k, k).uniform_(-0.05, 0.05, generator=gen)
         b = prefix + bn_name(name)
-        p[b + ".weight"] = torch.empty(cout).uniform_(-0.05, 0.05, generator=gen)
-        p[b + ".bias"] = torch.empty(cout).uniform_(-0.05, 0.05, generator=gen)
+        if init == "uniform":
+            p[prefix + name + ".weight"] = torch.empty(cout, cin, k, k).uniform_(-0.05, 0.05, generator=gen)
+            p[b + ".weight"] = torch.empty(cout).uniform_(-0.05, 0.05, generator=gen)
+            p[b + ".bias"] = torch.empty(cout).uniform_(-0.05, 0.05, generator=gen)
+        elif init == "kaiming":
+            p[prefix + name + ".weight"] = torch.empty(cout, cin, k, k).normal_(0.0, (2.0 / (cout * k * k)) ** 0.5, generator=gen)
+            p[b + ".weight"] = torch.ones(cout)
+            p[b + ".bias"] = torch.zeros(cout)
+        else:
+            raise ValueError(f"unknown init {init!r}")
     return p
 
 

@@ -29,9 +29,13 @@ Tensor = torch.Tensor
 
 def seqgan_step(gp: O.Params, dp: O.Params, captions: Tensor, u_sample: Sequence[Tensor], u_mc: Tensor, n_rollouts: int,
                 masks: Optional[Sequence[Tensor]], clip_norm: float = 5.0, gen_opt: Optional[O.AdamState] = None,
-                disc_opt: Optional[O.AdamState] = None, trunk_feat: Optional[Tensor] = None, num_rep: int = 64) -> Dict[str, object]:
+                disc_opt: Optional[O.AdamState] = None, trunk_feat: Optional[Tensor] = None, num_rep: int = 64,
+                force_Y: Optional[Tensor] = None) -> Dict[str, object]:
     """u_sample: L draws [B,V] for Y.  u_mc: [L, (L-1)*N*B, V] draws of the roll-outs, row (t-1)*N*B + n*B + b = roll-out n of
-    caption b from its prefix of length t.  masks: (mask_real, mask_fake) dropout keep masks of D's two training passes."""
+    caption b from its prefix of length t.  masks: (mask_real, mask_fake) dropout keep masks of D's two training passes.
+    ``force_Y`` [B,L] (test aid): the sampled captions to use instead of the oracle's own draw -- Y enters the losses only as data
+    (REINFORCE differentiates log G(y_t | ...) at GIVEN y), so where a bf16 near-tie flipped a sample on the GPU the gradients are
+    compared on the GPU's own Y."""
     bsz, seqlen = captions.shape
     vocab = gp["decoder.linear.weight"].shape[0]
     N = n_rollouts
@@ -41,6 +45,8 @@ def seqgan_step(gp: O.Params, dp: O.Params, captions: Tensor, u_sample: Sequence
     feats = O.encoder_head(g_leaf, trunk_feat) if trunk_feat is not None else O.start_features(g_leaf, bsz)
     with torch.no_grad():
         _, Y = O.decoder_sample(gp if trunk_feat is None else g_leaf, feats.detach(), seqlen, 1.0, u_sample)
+        if force_Y is not None:
+            Y = force_Y
         # Monte-Carlo roll-outs, one batch: rows ordered (prefix length t = 1..L-1, roll-out n, caption b)
         reps = (seqlen - 1) * N
         rewards = torch.empty(bsz, seqlen)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.library_path())
     for name in declared_symbols():
         assert hasattr(lib, name), f"libgicap.so does not export {name}"
-    assert _lib.load().gic_abi_version() == 2
+    assert _lib.load().gic_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_argument_validation_returns_status_not_crash():
@@ -93,3 +93,21 @@ def test_workspace_size_queries_match_the_host_allocations():
         assert lib.gic_disc_bwd_ws_bytes(ctypes.byref(dd), out) == 0
         assert list(out) == [nb(ws[k]) for k in ("dfeat", "dh", "dydrop", "dpooled", "demb")]
     assert lib.gic_decoder_state_bytes(None, None) == -1
+
+
+def test_fused_rollout_query_drives_the_rollout_buffers():
+    """gic_decoder_fused_rollout_rows (host-only) is the library's own path selection: shapes the fused step kernels decline
+    (V % 4, E % 8, H % 8) or batches beyond the row limit get the generic products' scratch, never a NULL the C side then rejects."""
+    from gan_image_captioning_amd import engine
+    for dt in (0, 1):
+        ok = engine.DecoderEngine(64, 32, 64, 1, dt)
+        assert ok.fused_rollout_rows() == 512
+        st = ok.alloc_rollout_state(8, 5, "meta")
+        assert st["part"] is not None and st["logits"] is None and st["gpre"] is None
+        st = ok.alloc_rollout_state(513, 5, "meta")
+        assert st["part"] is None and st["logits"] is not None and st["gpre"] is not None
+        for V, E, H in ((63, 32, 64), (64, 30, 64), (64, 32, 36), (9487, 300, 512)):
+            odd = engine.DecoderEngine(V, E, H, 1, dt)
+            assert odd.fused_rollout_rows() == 0
+            st = odd.alloc_rollout_state(8, 5, "meta")
+            assert st["part"] is None and tuple(st["logits"].shape) == (8, V) and tuple(st["gpre"].shape) == (8, 4 * H)

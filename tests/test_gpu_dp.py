@@ -13,6 +13,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def free_port() -> str:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def test_two_ranks_reproduce_the_single_process_step(tmp_path):
     worker = os.path.join(ROOT, "tests", "dp_gpu_worker.py")
     env = dict(os.environ, GIC_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
@@ -22,7 +29,7 @@ def test_two_ranks_reproduce_the_single_process_step(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     multi = str(tmp_path / "multi_%d.pt")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", worker, multi], env=env, capture_output=True, text=True, timeout=600)
+                        "--master-port", free_port(), worker, multi], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     one = torch.load(single % 0)
     r0, r1 = torch.load(multi % 0), torch.load(multi % 1)
@@ -51,7 +58,7 @@ def test_two_ranks_over_rccl_reproduce_the_single_process_step(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     multi = str(tmp_path / "multi_%d.pt")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29534", worker, multi], env=env, capture_output=True, text=True, timeout=600)
+                        "--master-port", free_port(), worker, multi], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     one = torch.load(single % 0)
     r0, r1 = torch.load(multi % 0), torch.load(multi % 1)
@@ -59,3 +66,23 @@ def test_two_ranks_over_rccl_reproduce_the_single_process_step(tmp_path):
     torch.testing.assert_close((r0["losses"] + r1["losses"]) / 2, one["losses"], rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(r0["disc"], one["disc"], rtol=1e-4, atol=2e-6)
     torch.testing.assert_close(r0["gen"], one["gen"], rtol=1e-4, atol=2e-6)
+
+
+def test_one_rank_rccl_communicator_drives_the_device_branch(tmp_path):
+    """SURVEY 8(e) on a one-GPU box: a 1-rank "nccl" (= RCCL) process group and GradReducer(force=True) execute the device branch --
+    side-stream ReduceOp.AVG behind an event, start / wait / wait_all -- and FusedAdvStep with that reducer attached (early bucket of
+    G's arena under BPTT, D's Adam gated on its own collective, the rest of G's arena) reproduces the reducer-less fused step BIT FOR
+    BIT in fp32 over two optimizer steps (an average over one rank is the identity)."""
+    worker = os.path.join(ROOT, "tests", "dp_rccl1_worker.py")
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port())
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GIC_DIST_BACKEND"):
+        env.pop(k, None)
+    out = str(tmp_path / "rccl1.pt")
+    r = subprocess.run([sys.executable, worker, out], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    res = torch.load(out)
+    assert res["backend"] == "nccl" and res["collectives"] >= 2 * 3 + 3, res["collectives"]      # per step: early bucket, D, 1-2 G spans
+    assert res["raw_identity"] and res["pending_after_wait_all"] == 0
+    assert torch.equal(res["plain"]["losses"], res["dp"]["losses"])
+    assert torch.equal(res["plain"]["gen"], res["dp"]["gen"]) and torch.equal(res["plain"]["disc"], res["dp"]["disc"])
+    assert torch.equal(res["plain"]["ids"], res["dp"]["ids"])

@@ -201,6 +201,42 @@ def test_trunk_forward_bf16_at_bench_resolution(dev, monkeypatch):
     assert rel_l2(got_v, bv * (1 - 0.9 ** 3) + 0.9 ** 3) < 2e-2
 
 
+def test_trunk_forward_bf16_under_a_realistic_init(dev):
+    """The per-stage bf16 budget of test_cfg2_composed_step_bf16_vs_oracle (up to 1.4e-1 at stage 3) belongs to the reference's
+    U(-0.05, 0.05) init of EVERY tensor (generator.py:116-123: BatchNorm gamma ~ +-0.03, so a normalised output's mean is comparable
+    to its spread and each mean subtraction amplifies the rounding of its input).  Under the published ResNet init (Kaiming conv
+    weights, gamma 1, beta 0 -- the statistics of a trained trunk) the same kernels at the same shapes stay within 2e-2 relative L2
+    of the fp32 oracle at EVERY stage and in the pooled feature; the uniform init on the same images is measured beside it."""
+    from gan_image_captioning_amd.trunk import ResNetTrunk
+    N, S = 16, 224
+    report = {}
+    for init in ("kaiming", "uniform"):
+        g = torch.Generator().manual_seed(2024)
+        tp = OE.make_trunk_params("resnet50", g, init=init)
+        images = torch.randn(N, 3, S, S, generator=g)
+        taps = {}
+        want = OE.trunk_forward(tp, images, "resnet50", taps=taps)
+        trunk = ResNetTrunk("resnet50")
+        trunk.load_state_dict({k[len("encoder.resnet."):]: v for k, v in tp.items()}, strict=False)
+        trunk = trunk.to(dev).train()
+        feat = trunk(images.to(dev), 1).float().clone()
+        torch.cuda.synchronize()
+        pb = trunk._plan._bufs[(N, S)]
+        last, i = [], -1
+        for stage in trunk.stages():
+            i += len(stage)
+            last.append(i)
+        errs = {"stem": rel_l2(pb["x0"].float().permute(0, 3, 1, 2), taps["stem"])}
+        for si, bi in enumerate(last):
+            errs[f"stage{si}"] = rel_l2(pb["blocks"][bi]["out"].float().permute(0, 3, 1, 2), taps[f"stage{si}"])
+        errs["pooled"] = rel_l2(feat, want)
+        report[init] = errs
+    print("bf16 trunk rel-L2 per stage:", report)
+    for k, v in report["kaiming"].items():
+        assert v < 2e-2, f"realistic init, {k}: rel L2 {v:.3e}"
+    assert report["uniform"]["stage3"] > 2 * report["kaiming"]["stage3"]      # the wide budget is the init's, not the kernels'
+
+
 @pytest.mark.parametrize("arch,S,N", [("resnet18", 64, 4), ("resnet50", 64, 2), ("resnet18", 96, 2)])
 def test_trunk_forward_f32_matches_oracle(dev, arch, S, N):
     from gan_image_captioning_amd.trunk import ResNetTrunk

@@ -82,34 +82,6 @@ def _decoder(E, gp, dt):
     return E.DecoderEngine(V, Em, H, nl, dt)
 
 
-@pytest.mark.parametrize("name", ["tiny_rep2", "cfg1"])
-def test_persistent_rollout_kernel_matches_golden(E, dev, name):
-    """The opt-in single-launch roll-out (grid barriers between the step phases; off by default) against the
-    reference's own outputs: ids exact, probabilities rtol 1e-4; its barrier counter ends at (2L - 1) x grid and its error flag at 0."""
-    from gan_image_captioning_amd import _lib
-    g = Golden(name)
-    gp, _ = initial_params(g)
-    m = g.meta
-    eng = _decoder(E, gp, 0)
-    params = dec_params(gp, dev)
-    feats = O.start_features(gp, m["B"]).to(dev)
-    u = g.t("s0/u").to(dev)
-    _lib.load().gic_debug_decoder_step(8)
-    try:
-        st = eng.alloc_state(m["B"], m["L"], dev)
-        out, ids, _ = eng.sample_fwd(params, feats, m["L"], m["temperatures"][0], noise_u=u, state=st)
-        torch.cuda.synchronize()
-    finally:
-        _lib.load().gic_debug_decoder_step(0)
-    assert torch.equal(ids.cpu(), g.t("s0/ids")), "sampled token ids differ from the reference"
-    close(out, g.t("s0/probs"), rtol=1e-4, atol_scale=1e-6, what="probs")
-    assert O.num_lstm_layers(gp) == 1 and eng.V % 4 == 0        # shapes the persistent kernel takes
-    nblk = (eng.V + 63) // 64
-    off = ((2 * m["L"] * m["B"] * nblk + 1) & ~1) + 2 * m["L"] * m["B"]
-    words = st["part"].view(torch.int32)[off:off + 2].tolist()
-    assert words[1] == 0 and words[0] > 0 and words[0] % (2 * m["L"] - 1) == 0, words
-
-
 @pytest.mark.parametrize("name", ["tiny", "tiny_scaled", "tiny_rep2", "cfg1"])
 def test_decoder_sample_fwd_f32_matches_golden(E, dev, name):
     """fp32 parity mode against the reference's own outputs: ids exact, probabilities rtol 1e-4."""

@@ -23,7 +23,10 @@ def _problem(B, L, V, E, H, NL, N, nf, seed):
     return gp, dp, caps, us, umc, masks
 
 
-@pytest.mark.parametrize("shape", [(4, 5, 52, 8, 16, 1, 3), (6, 6, 64, 16, 32, 2, 2), (8, 6, 64, 16, 32, 1, 14)])   # the last one: 560 roll-outs, resumed
+# (8, 6, 64, 16, 32, 1, 14): 560 roll-outs, resumed.  The last two: shapes the fused step kernels decline (V % 4, E % 8, H % 8 != 0: any
+# real vocabulary, --gen-embed-dim 300) -- every pass runs as generic products; the resumed one copies f32 rows of 26 floats (104 B: 4-byte pieces)
+@pytest.mark.parametrize("shape", [(4, 5, 52, 8, 16, 1, 3), (6, 6, 64, 16, 32, 2, 2), (8, 6, 64, 16, 32, 1, 14), (4, 5, 51, 6, 20, 1, 3),
+                                   (8, 6, 63, 6, 20, 1, 14)])
 def test_seqgan_step_f32_matches_oracle(shape):
     from gan_image_captioning_amd.args import default_args
     from gan_image_captioning_amd.training import GANInstructor
@@ -110,3 +113,120 @@ def test_seqgan_rollouts_keep_their_prefix_and_run_at_scale():
     torch.cuda.synchronize()
     assert torch.isfinite(losses).all()
     assert not torch.equal(before[0], inst.gen_arena.flat) and not torch.equal(before[1], inst.disc_arena.flat)
+
+
+@pytest.mark.parametrize("E_,H_,dt", [(7, 20, "bf16"), (6, 20, "bf16"), (7, 20, "fp32"), (16, 32, "bf16")])
+def test_resumed_rollouts_copy_whole_rows_at_any_row_size(E_, H_, dt):
+    """rollout_join moves [x | h] rows in 16-, 4- or 2-byte pieces by the row size (bf16 rows of E + H = 27 elements are 54 bytes): a
+    resumed roll-out must start from exactly the state the teacher-forced pass reached.  Checked through the first sampled token of
+    every resumed row: with the same device noise it equals the one the non-resumed roll-out (which recomputes its prefix with the
+    same generic products) draws, up to rare bf16 near-ties between the two routes."""
+    from gan_image_captioning_amd import engine as E
+    from gan_image_captioning_amd import _lib
+    dev = torch.device("cuda:0")
+    B, L, V, N = 8, 6, 63, 14                              # 560 rows > 512: the generic-product path
+    g = torch.Generator().manual_seed(5)
+    gp = {k: v * 6 for k, v in O.make_gen_params(V, E_, H_, 1, g).items()}
+    dec = E.DecoderEngine(V, E_, H_, 1, _lib.BF16 if dt == "bf16" else _lib.F32)
+    params = [gp[n].to(dev) for n in dec_param_names(1)]
+    feats = (torch.randn(B, E_, generator=g) * 0.3).to(dev)
+    _, Y, _ = dec.sample_fwd(params, feats, L, 1.0, seed=3, ids_only=True)
+    reps = (L - 1) * N
+    flen = torch.arange(1, L, device=dev, dtype=torch.int32).repeat_interleave(N * B)
+    big, force = feats.repeat(reps, 1), Y.repeat(reps, 1)
+    _, mc, _ = dec.sample_fwd(params, big, L, 1.0, seed=4, ids_only=True, force_ids=force, force_len=flen)
+    _, _, st_y = dec.sample_fwd(params, feats, L, 1.0, pretrain=True, force_ids=Y)
+    _, mc2, _ = dec.sample_fwd(params, big, L, 1.0, seed=4, ids_only=True, force_ids=force, force_len=flen,
+                               resume=(st_y, B, [min(t, L - 1) * N * B for t in range(L)]))
+    torch.cuda.synchronize()
+    mc, mc2, Yc = mc.view(L - 1, N, B, L).cpu(), mc2.view(L - 1, N, B, L).cpu(), Y.cpu()
+    for t in range(1, L):
+        assert torch.equal(mc2[t - 1, :, :, :t], Yc[None, :, :t].expand(N, B, t)), f"resumed: prefix of length {t} not kept"
+    agree = float((mc2 == mc).float().mean())
+    assert agree > (0.999 if dt == "fp32" else 0.9), agree
+
+
+def test_cfg5_step_bf16_at_its_baseline_shape_vs_oracle():
+    """BASELINE configs[4] at its per-GPU shape, composed as `bench.py --workload cfg5` times it: --adv-mode seqgan with
+    --conditional-gan 1 (ResNet-50-shaped trunk at 224x224), B=32 captions, L=20, V=10000, E=H=512, bf16 compute; N=2 Monte-Carlo
+    roll-outs per prefix with EXPLICIT noise (19 * 2 * 32 = 1216 roll-out rows > the fused kernels' 512: the resumed generic-product
+    path is engaged) against oracle/cpu_seqgan.py on oracle/cpu_encoder.py's trunk features.  The decoder and D weights are scaled
+    (x3 / x5) so that the sampler is not pure noise and the reward model is informative.  Limits are written below."""
+    import json
+    import os
+    from oracle import cpu_encoder as OE
+    from tests.gpu_util import rel_l2
+    from gan_image_captioning_amd.args import default_args
+    from gan_image_captioning_amd.training import GANInstructor
+    B, L, V, E, H, N = 32, 20, 10000, 512, 512, 2
+    g = torch.Generator().manual_seed(515)
+    gp = O.make_gen_params(V, E, H, 1, g, trunk_feat_dim=OE.out_features("resnet50"))
+    gp = {k: (v * 3 if k.startswith("decoder.") else v) for k, v in gp.items()}
+    dp = {k: v * 5 for k, v in O.make_disc_params(V, g).items()}       # x5: D's scores spread (std 3e-3) without saturating the sigmoid
+    tp = OE.make_trunk_params("resnet50", g)
+    caps = O.make_captions(B, L, V, g)
+    images = torch.randn(B, 3, 224, 224, generator=g)
+    us = [torch.empty(B, V).uniform_(0, 1, generator=g) for _ in range(L)]
+    umc = torch.empty(L, (L - 1) * N * B, V).uniform_(0, 1, generator=g)
+    masks = [torch.empty(B * 64, 900).bernoulli_(0.8, generator=g) for _ in range(2)]
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    with torch.no_grad():
+        feat = OE.trunk_forward(tp, images, "resnet50")
+
+    args = default_args(vocab_size=V, gen_embed_dim=E, gen_hidden_dim=H, conditional_gan=1, encoder_arch="resnet50", adv_mode="seqgan",
+                        mc_rollouts=N, compute_dtype="bf16", adv_train_batch_size=B, image_size=224, device="cuda", log_file=None,
+                        model_dir=None, save_dir=None)
+    inst = GANInstructor(args, None, None)
+    dev = args.device
+    enc = inst.gen.encoder
+    with torch.no_grad():
+        for n, p in zip(dec_param_names(1), inst.gen.decoder.param_list()):
+            p.copy_(gp[n])
+        for n, p in zip(disc_param_names(3), inst.disc.param_list()):
+            p.copy_(dp[n])
+        enc.resnet.load_state_dict({k[len("encoder.resnet."):]: v for k, v in tp.items()}, strict=False)
+        for n in ("linear.weight", "linear.bias", "bn.weight", "bn.bias"):
+            mod, attr = n.split(".")
+            getattr(getattr(enc, mod), attr).copy_(gp["encoder." + n])
+    inst.gen.train(); inst.disc.train()
+    out = inst.seqgan(images.to(dev), caps.to(dev), L, True, torch.stack(us).to(dev), umc.to(dev), [m.to(dev) for m in masks], opt_step=False)
+    torch.cuda.synchronize()
+    Y = out["ids"].cpu()
+    # the oracle is fed the GPU's own trunk features (the trunk's bf16 budget is test_cfg2_composed's and test_trunk_forward_bf16_*'s
+    # subject; here everything downstream of it is) and, where a bf16 near-tie flipped a sample, the GPU's own Y
+    feat_gpu = enc.resnet._plan._bufs[(B, 224)]["feat"].float().cpu()
+    report = {"trunk_pooled_rel_l2": rel_l2(feat_gpu, feat)}
+    ref = S.seqgan_step(dict(gp), dict(dp), caps, us, umc, N, masks, trunk_feat=feat_gpu)
+    report["Y_match_rate"] = float((Y == ref["Y"]).float().mean())
+    if report["Y_match_rate"] < 1.0:
+        ref = S.seqgan_step(dict(gp), dict(dp), caps, us, umc, N, masks, trunk_feat=feat_gpu, force_Y=Y)
+    report["rewards_std"] = float(ref["rewards"].std())
+    report["rewards_rel_l2"] = rel_l2(out["rewards"].cpu(), ref["rewards"])
+    report["rewards_centered_rel_l2"] = rel_l2(out["rewards"].cpu() - ref["rewards"].mean(), ref["rewards"] - ref["rewards"].mean())
+    report["logits_rel_l2"] = rel_l2(out["logits"].float().cpu(), ref["logits"])
+    gl, dl = (float(v) for v in out["losses"])
+    report.update(g_loss=gl, g_loss_ref=ref["g_loss"], d_loss=dl, d_loss_ref=ref["d_loss"])
+    ggot = {n: p.grad for n, p in zip(dec_param_names(1), inst.gen.decoder.param_list())}
+    ggot.update({"encoder.linear.weight": enc.linear.weight.grad, "encoder.bn.weight": enc.bn.weight.grad, "encoder.bn.bias": enc.bn.bias.grad})
+    dgot = {n: p.grad for n, p in zip(disc_param_names(3), inst.disc.param_list())}
+    for n in list(dec_param_names(1)) + ["encoder.linear.weight", "encoder.bn.weight", "encoder.bn.bias"]:
+        report["g_grad_rel_l2/" + n] = rel_l2(ggot[n], ref["g_grads_raw"][n])
+    for n in ("highway.weight", "feature2out.weight", "out2logits.weight", "embeddings.weight", "convs.0.weight", "convs.2.weight"):
+        report["d_grad_rel_l2/" + n] = rel_l2(dgot[n], ref["d_grads_raw"][n])
+    print("cfg5 composed parity:", json.dumps(report))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", "cfg5_parity.json"), "w") as fh:
+            json.dump(report, fh, indent=1)
+    except OSError:
+        pass
+    assert report["Y_match_rate"] >= 0.9
+    assert report["rewards_std"] > 5e-4                       # the rewards actually differ between positions
+    assert report["rewards_rel_l2"] < 1e-2
+    # the informative part of the rewards (their spread around the mean): a roll-out token flipped by a bf16 near-tie moves one of the
+    # N = 2 completions of one (caption, position), i.e. that reward by about one standard deviation
+    assert report["rewards_centered_rel_l2"] < 5e-1
+    assert report["logits_rel_l2"] < 2e-2
+    assert gl == pytest.approx(ref["g_loss"], rel=2e-2) and dl == pytest.approx(ref["d_loss"], rel=2e-2)
+    bad = [(k, v) for k, v in report.items() if k.startswith(("g_grad_rel_l2/", "d_grad_rel_l2/")) and not v < 1e-1]
+    assert not bad, bad

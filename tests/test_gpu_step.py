@@ -5,7 +5,7 @@ drivers (``fused`` kernel sequence and ``autograd`` module API), fp32 parity mod
 Per step (parameters teacher-forced to the reference's trajectory, like tests/test_oracle_golden.py):
 token ids exact; probabilities / logits rtol 1e-4; losses rel 1e-5; gradient norms rel 1e-4; raw
 gradients rtol 2e-3 (+1e-4 x max entry); optimizer: clip+Adam from the golden gradients reproduces the
-reference's post-step weights to 1e-6 (tests/test_gpu_kernels.py) and end-to-end stays within lr.
+reference's post-step weights to 1e-6 (tests/test_gpu_kernels.py), and so does the end-to-end step (post/ weights of the `full` goldens).
 """
 import pytest
 import torch
@@ -100,9 +100,20 @@ def test_adv_step_matches_reference(name, impl):
         torch.cuda.synchronize()
         if full:
             post = g.group(pre + "post/")
+            # the reference's own post-step weights: Adam's update is lr * m_hat / (sqrt(v_hat) + 1e-8), i.e. +-lr wherever |g| >> 1e-8,
+            # so 1e-6 (1 % of lr) pins the sign and the clip scale of every gradient entry and the moments' arithmetic; an entry whose
+            # gradient is ~1e-8 or that carries a re-routed max-pool near-tie may differ (counted: <= 0.1 % of a tensor, never > 2.1 lr);
+            # an optimizer that does nothing fails (the weights must have MOVED by ~lr from the pre-step values)
+            pre_w = {**gp, **dp}
             for n, p in list(zip(gnames, inst.gen.decoder.param_list())) + list(zip(dnames, inst.disc.param_list())):
                 lr = m["gen_lr"] if n in gnames else m["disc_lr"]
-                assert float((p.detach().cpu() - post[n]).abs().max()) <= 1.05 * lr, n
+                got_w = p.detach().cpu()
+                err = (got_w - post[n]).abs()
+                moved_ref = float((post[n] - pre_w[n]).abs().max())
+                bad = float((err > 1e-6).float().mean())
+                assert bad <= 1e-3 and float(err.max()) <= 2.1 * lr, (n, bad, float(err.max()))
+                if moved_ref > 0.5 * lr:
+                    assert float((got_w - pre_w[n]).abs().max()) > 0.5 * lr, f"{n}: the optimizer did not move the weights"
             gp = {n: post[n] for n in gnames}
             dp = {n: post[n] for n in dnames}
         else:

@@ -28,9 +28,9 @@ def timed(fn, n=20):
 
 from gan_image_captioning_amd import _lib
 # ablation bits (gic_debug_decoder_step): 1 = lstm_step's weight loads, 2 = lstm_step's activation staging and vocab_step's MFMA loop,
-# 4 = vocab_step's staging (weights and h) removed; 8 = the opt-in persistent kernel (one launch, grid barriers between the phases)
+# 4 = vocab_step's staging (weights and h) removed
 for name, part, dbg in (("fused", True, 0), ("fused-noW", True, 1), ("fused-noA", True, 2), ("fused-noWA", True, 3), ("fused-noStage", True, 4),
-                        ("fused-none", True, 7), ("persistent", True, 8), ("generic", False, 0)):
+                        ("fused-none", True, 7), ("generic", False, 0)):
     _lib.load().gic_debug_decoder_step(dbg)
     st = eng.alloc_state(B, L, dev)
     if not part:
