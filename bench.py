@@ -142,7 +142,7 @@ def roofline_probe(inst, args, cgan, step=None):
         from gan_image_captioning_amd import encoder_engine
         traffic = None
         try:     # HBM bytes per launch: NOT measured by this run -- read from the committed rocprofv3 --pmc passes of this command
-            name = "r02_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) else "r01_pmc_traffic.json"
+            name = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))[-1]      # the latest round's
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 traffic = json.load(fh)["conv_bnstats"]["hbm_bytes_per_launch"]
         except Exception:
@@ -167,13 +167,28 @@ def roofline_probe(inst, args, cgan, step=None):
             "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "ms_per_launch": round(ms, 5)}
 
 
+def usable_cores() -> int:
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:               # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fh.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+        else:
+            n = min(n, 16)                                       # no visible quota: the documented share of a one-GPU box
+    except (OSError, ValueError):
+        n = min(n, 16)
+    return n
+
+
 def cpu_baseline(a, cgan):
     """The CPU oracle on a bounded sample of the same workload: `cpu_steps` full steps at the same batch, median; with the
     encoder in the step (the headline workload) and without it (the part the reference itself owns: torchvision's trunk is not in
     the reference tree)."""
     from oracle import cpu_step as O
-    # BASELINE.md section 2: all host cores of the box (the affinity mask of this process: what it may actually use)
-    cores = len(os.sched_getaffinity(0))
+    # BASELINE.md section 2 asks for all host cores; what this process may actually USE is the smaller of its affinity mask and its
+    # cgroup CPU quota (a one-GPU box hands out a 16-core share of a many-core host: 128 threads on that share ran 100x slower)
+    cores = usable_cores()
     torch.set_num_threads(cores)
     import statistics
     g = torch.Generator().manual_seed(1008)

@@ -48,7 +48,16 @@ class DecoderState(C.Structure):
 
 class DecoderSampleOpts(C.Structure):
     _fields_ = [("h0", c_void_p), ("c0", c_void_p), ("force_ids", c_void_p), ("force_len", c_void_p), ("no_state", C.c_int32),
-                ("resume_from", c_void_p), ("resume_B", C.c_int32), ("host_active_rows", c_void_p)]
+                ("resume_from", c_void_p), ("resume_B", C.c_int32), ("host_active_rows", c_void_p),
+                ("dev_scalars", c_void_p), ("seed_slot", C.c_int32)]
+
+
+STEP_SEEDS = 6
+
+
+class StepScalars(C.Structure):
+    """gic_step_scalars: the per-step scalars a replayed step graph reads from device memory."""
+    _fields_ = [("temperature", C.c_float), ("reserved", C.c_uint32), ("seed", C.c_uint64 * STEP_SEEDS)]
 
 
 class DecoderBwdWs(C.Structure):
@@ -133,7 +142,8 @@ _SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p]),
     "gic_decoder_sample_bwd": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), _P(DecoderState),
                                          _P(DecoderBwdWs), c_void_p, c_void_p, c_void_p, C.c_float, C.c_int,
-                                         _P(DecoderGrads), C.c_int, c_void_p]),
+                                         _P(DecoderGrads), C.c_int, c_void_p, c_void_p]),
+    "gic_step_scalars_set": (C.c_int, [c_void_p, _P(StepScalars), c_void_p]),
     "gic_debug_decoder_step": (None, [C.c_int]),
     "gic_decoder_fused_rollout_rows": (C.c_int, [_P(DecoderDims), c_void_p]),
     "gic_attn_prepare": (C.c_int, [_P(AttnDims), _P(AttnParams), _P(AttnShadow), c_void_p]),
@@ -145,9 +155,9 @@ _SIGNATURES = {
     "gic_embedding_bwd": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int, c_void_p]),
     "gic_disc_prepare": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), c_void_p]),
     "gic_disc_fwd": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), _P(DiscState), c_void_p, C.c_int64, c_void_p,
-                               C.c_int, c_void_p, C.c_uint64, c_void_p, c_void_p]),
+                               C.c_int, c_void_p, C.c_uint64, c_void_p, c_void_p, C.c_int, c_void_p]),
     "gic_disc_fwd_redrop": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), _P(DiscState), _P(DiscState), C.c_int, c_void_p,
-                            C.c_uint64, c_void_p, c_void_p]),
+                            C.c_uint64, c_void_p, c_void_p, C.c_int, c_void_p]),
     "gic_disc_bwd": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), _P(DiscState), _P(DiscBwdWs), c_void_p,
                                C.c_int64, c_void_p, C.c_int, c_void_p, _P(DiscGrads), C.c_int, c_void_p, C.c_int64, c_void_p]),
     "gic_pack_image": (C.c_int, [c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),

@@ -9,9 +9,15 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB = os.path.join(CSRC, "libgicap.so")
+# GIC_LIB_VARIANT=stamps: the tools build (-DGIC_STAMPS: per-phase s_memtime stamps, tools/*_stamps.py) as csrc/libgicap_stamps.so with
+# its own object directory, beside the product library; GIC_LIB_VARIANT=nt: the trunk's activation loads with the nt cache policy
+# (common.h GIC_TRUNK_NT; a measurement build).  Tests, smoke() and the driver's bench.py never set it
+VARIANT = os.environ.get("GIC_LIB_VARIANT", "")
+LIB = os.path.join(CSRC, f"libgicap_{VARIANT}.so" if VARIANT else "libgicap.so")
+OBJDIR = os.path.join(CSRC, f"build_{VARIANT}" if VARIANT else "build")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"] + os.environ.get("GIC_EXTRA_FLAGS", "").split()
+FLAGS = (["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"] + (["-DGIC_STAMPS"] if VARIANT == "stamps" else []) + (["-DGIC_TRUNK_NT=2"] if VARIANT == "nt" else [])
+         + os.environ.get("GIC_EXTRA_FLAGS", "").split())
 
 
 def _hipcc() -> str:
@@ -31,8 +37,8 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile what is stale.  An exclusive file lock serialises concurrent callers (one rank per GPU under torchrun)."""
     import fcntl
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
-    with open(os.path.join(CSRC, "build", ".lock"), "w") as lock:
+    os.makedirs(OBJDIR, exist_ok=True)
+    with open(os.path.join(OBJDIR, ".lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             return _build_locked(force, verbose)
@@ -44,8 +50,7 @@ def _build_locked(force: bool, verbose: bool) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [
         os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "gicap.h")]
-    objdir = os.path.join(CSRC, "build")
-    os.makedirs(objdir, exist_ok=True)
+    objdir = OBJDIR
     hipcc = _hipcc()
 
     def compile_one(src: str) -> str:

@@ -303,7 +303,7 @@ int attn_bwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S
                const gic_attn_grads* G, hipStream_t stream) {
   const int B = c.B, L = c.L, V = c.V, E = c.E, H = c.H, C = c.C, A = c.A;
   const long ld = c.ldx(), BL = (long)B * L;
-  GIC_PROPAGATE(decoder_output_bwd(c.dt, B, L, V, H, probs, d_out, temperature, pretrain, ws->dlogits, S->wout, st->hout, ws->dhout,
+  GIC_PROPAGATE(decoder_output_bwd(c.dt, B, L, V, H, probs, d_out, temperature, nullptr, pretrain, ws->dlogits, S->wout, st->hout, ws->dhout,
                                    G->w_out, G->b_out, stream));
   GIC_PROPAGATE(fill_zero(ws->dc, (size_t)B * H * sizeof(float), stream));
   GIC_PROPAGATE(fill_zero(ws->dfproj, (size_t)B * c.P * A * sizeof(float), stream));

@@ -16,6 +16,14 @@ enum DType { DT_F32 = 0, DT_BF16 = 1 };
 
 static constexpr int WAVE = 64;   // CDNA wavefront
 
+// Cache policy (aux) of the trunk's once-read activation loads (LDS-DMA of the A operand in the convolution kernels): 0 = default,
+// 2 = nt (streaming: the lines are the first to leave L2).  A build-time switch (GIC_LIB_VARIANT=nt, tools) for measuring whether the
+// trunk pass on its stream evicts the decoder's weights from the XCD L2s; the product build leaves it at 0
+// unless the measurement says otherwise.
+#ifndef GIC_TRUNK_NT
+#define GIC_TRUNK_NT 0
+#endif
+
 // ---------------------------------------------------------------- status
 enum Status {
   GIC_OK = 0,

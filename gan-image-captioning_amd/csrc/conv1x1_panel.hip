@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512) void conv1x1_panel_kernel(const PanelDesc d) {
   for (int i = 0; i < CA; ++i) {
     const int row = bm0 + (tid >> 3) + 64 * (i & 1);
     const unsigned voff = row < M ? (unsigned)(row * d.lda + (i >> 1) * 64 + kc) * 2u : OOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(smem + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(smem + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, GIC_TRUNK_NT);
   }
   auto issue_w = [&](const int nt, const int st) {                      // weight tile nt: piece i = K tile i, rows tid >> 3
     const int n = nt * BN + (tid >> 3);

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const StreamDesc d)
     for (int i = 0; i < CA; ++i) {
       const int row = bm0 + (tid >> 3) + 64 * (i & 1);
       const unsigned voff = (tile < d.tiles_m && row < M) ? (unsigned)(row * d.lda + (i >> 1) * 64 + kc) * 2u : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(smem + st * A_BYTES + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(smem + st * A_BYTES + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, GIC_TRUNK_NT);
     }
   };
   // ---- prologue: the weights of this workgroup's output channels (resident), the first NS - 1 row tiles

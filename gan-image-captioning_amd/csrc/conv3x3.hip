@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchDesc d) {
   }
   auto issue_patch = [&](const int i, const int chunk, const int buf) {
     const unsigned voff = (poff[i] >= 0 && chunk < pa.nchunks) ? (unsigned)(poff[i] + chunk * 64) * 2u : OOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(smem + buf * PATCH + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(smem + buf * PATCH + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, GIC_TRUNK_NT);
   };
   // ---- weight tile of one K step (tap, chunk): rows (tid >> 3) + 64 i of the BN output channels, 64 channels = 128 bytes each
   const int kc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
@@ -281,6 +281,9 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const PatchDesc d) {
       read_half(patch, tapoff, t % 3, 1, fa1, fb1);
       __builtin_amdgcn_sched_barrier(0);
       mfma_half(fa0, fb0);
+      // keep these MFMAs ABOVE the next step's wait + barrier: they cover the latency of the half-1 reads just issued (neither the
+      // inline-asm wait nor s_barrier orders register-only instructions, and the scheduler sank seven of the eight below the barrier)
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   mfma_half(fa1, fb1);

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(512) void conv_stem_kernel(const StemDesc d) {
       const int j = first + (w >> 1);
       const int piece = (w & 1) * 64 + lane;
       const unsigned voff = (j < d.H && piece < row_pieces) ? (unsigned)((n_img * d.H + j) * W * 4 + piece * 8) * 2u : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(smem + (j % kRing) * kSlot + (w & 1) * 1024), 16, (int)voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(smem + (j % kRing) * kSlot + (w & 1) * 1024), 16, (int)voff, 0, 0, GIC_TRUNK_NT);
     }
   };
   // ---- prologue: the rows of the first 1 + kAhead output rows (7 + 2 kAhead = 13, in pairs), the weights

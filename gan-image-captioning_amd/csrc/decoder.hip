@@ -256,8 +256,9 @@ __global__ __launch_bounds__(1024) void gumbel_softmax_argmax_reg_kernel(
 // ---- softmax backward: dlogit = T * p * (dp - sum(dp*p))   (one block per (b,t) row)
 template <typename TA>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const TA* __restrict__ p, const TA* __restrict__ dp,
-                                                           TA* __restrict__ dl, float temperature, int V) {
+                                                           TA* __restrict__ dl, float temperature_val, const float* __restrict__ t_dev, int V) {
   __shared__ float red[16];
+  const float temperature = t_dev ? *t_dev : temperature_val;
   const long row = blockIdx.x;
   const TA* pr = p + row * V;
   const TA* dr = dp + row * V;
@@ -274,9 +275,10 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const TA* __restrict__
 // V <= 256 * NCH * (16 / sizeof)); the scalar kernel above reads both rows twice, two bytes per lane at a time.
 template <typename TA, int NCH>
 __global__ __launch_bounds__(256) void softmax_bwd_vec_kernel(const TA* __restrict__ p, const TA* __restrict__ dp,
-                                                               TA* __restrict__ dl, float temperature, int V) {
+                                                               TA* __restrict__ dl, float temperature_val, const float* __restrict__ t_dev, int V) {
   constexpr int VN = 16 / (int)sizeof(TA);
   __shared__ float red[16];
+  const float temperature = t_dev ? *t_dev : temperature_val;
   const long row = blockIdx.x;
   const int nch = V / VN;
   TA pv[NCH][VN], dv[NCH][VN];
@@ -416,6 +418,7 @@ int sample_fwd_fused(const Ctx& c, const gic_decoder_params* P, const gic_decode
     v.wout = S->wout; v.bias = P->b_out;
     v.u = noise_u ? noise_u + (long)t * B * V : nullptr;
     v.seed = seed; v.rng_stream = (uint64_t)t; v.temperature = temperature; v.pretrain = pretrain;
+    if (opt && opt->dev_scalars) { v.t_dev = &opt->dev_scalars->temperature; v.seed_dev = &opt->dev_scalars->seed[opt->seed_slot]; }
     v.out = out ? (void*)((TA*)out + (long)t * V) : nullptr; v.out_stride = (long)L * V;
     v.part_m = part_m + (long)t * B * nblk; v.part_s = part_s + (long)t * B * nblk; v.rowkey = rowkey + (long)t * B;
     v.nblk = nblk; v.B = B; v.V = V; v.H = H;
@@ -440,6 +443,11 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
   // roll-out batches) they are large GEMMs and the generic 128-row-tile kernels are the efficient form
   if (st->part && B <= decoder_step_max_rows() && !(opt && opt->resume_from) && decoder_step_supported(c.dt, V, E, H, NL))
     return sample_fwd_fused<TA>(c, P, S, st, noise_u, seed, temperature, pretrain, out, ids, opt, stream);
+  if (opt && opt->dev_scalars) {
+    set_last_error("decoder_sample_fwd: device-resident step scalars need the fused step kernels (state->part, B <= %d, V %% 4 == 0, E, H %% 8 == 0)",
+                   decoder_step_max_rows());
+    return GIC_ERR_UNSUPPORTED;
+  }
   GIC_CHECK_ARG(st->logits && st->gpre, "decoder_sample_fwd: the unfused path needs state->logits and state->gpre");
   const bool keep = !(opt && opt->no_state);
   const int64_t* f_ids = opt ? opt->force_ids : nullptr;
@@ -521,13 +529,13 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
 template <typename TA>
 int sample_bwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_shadow* S, const gic_decoder_state* st,
                  const gic_decoder_bwd_ws* ws, const void* probs, const int64_t* ids, const void* d_out,
-                 float temperature, int pretrain, const gic_decoder_grads* G, int phases, hipStream_t stream) {
+                 float temperature, const float* t_dev, int pretrain, const gic_decoder_grads* G, int phases, hipStream_t stream) {
   const int B = c.B, L = c.L, V = c.V, E = c.E, H = c.H, NL = c.NL;
   const long BL = (long)B * L;
   const int pw_grid = cdiv((long)B * H, 256);
   // 1. + 2. output layer: d_logits [B,L,V], d_hout = d_logits W_out, dW_out = d_logits^T hout, db_out = colsum(d_logits)
   if (phases & GIC_DECODER_BWD_OUTPUT)
-    GIC_PROPAGATE(decoder_output_bwd(c.dt, B, L, V, H, probs, d_out, temperature, pretrain, ws->dlogits, S->wout, st->hout, ws->dhout,
+    GIC_PROPAGATE(decoder_output_bwd(c.dt, B, L, V, H, probs, d_out, temperature, t_dev, pretrain, ws->dlogits, S->wout, st->hout, ws->dhout,
                                      G->w_out, G->b_out, stream));
   if (!(phases & GIC_DECODER_BWD_RECURRENT)) return GIC_OK;
   // 3. BPTT
@@ -628,7 +636,7 @@ __global__ void embed_scatter_time_kernel(const float* __restrict__ dxh0, long l
 
 // Output layer of the decoder, backward (shared by the LSTM and the attention decoder): softmax/Gumbel backward (adversarial mode),
 // d_hout, and the complete gradients of the vocabulary projection.
-int decoder_output_bwd(int dt, int B, int L, int V, int H, const void* probs, const void* d_out, float temperature, int pretrain,
+int decoder_output_bwd(int dt, int B, int L, int V, int H, const void* probs, const void* d_out, float temperature, const float* t_dev, int pretrain,
                        void* dlogits_ws, const void* wout, const void* hout, float* dhout, float* d_wout, float* d_bout, hipStream_t stream) {
   const long BL = (long)B * L;
   const void* dlog = pretrain ? d_out : (const void*)dlogits_ws;
@@ -637,20 +645,20 @@ int decoder_output_bwd(int dt, int B, int L, int V, int H, const void* probs, co
     if (dt == DT_F32) {
       if (al && V % 4 == 0 && V <= 256 * 8 * 4)
         hipLaunchKernelGGL((softmax_bwd_vec_kernel<float, 8>), dim3((unsigned)BL), dim3(256), 0, stream, (const float*)probs, (const float*)d_out,
-                           (float*)dlogits_ws, temperature, V);
+                           (float*)dlogits_ws, temperature, t_dev, V);
       else
         hipLaunchKernelGGL((softmax_bwd_kernel<float>), dim3((unsigned)BL), dim3(256), 0, stream, (const float*)probs, (const float*)d_out,
-                           (float*)dlogits_ws, temperature, V);
+                           (float*)dlogits_ws, temperature, t_dev, V);
     } else {
       if (al && V % 8 == 0 && V <= 256 * 5 * 8)
         hipLaunchKernelGGL((softmax_bwd_vec_kernel<bf16_t, 5>), dim3((unsigned)BL), dim3(256), 0, stream, (const bf16_t*)probs, (const bf16_t*)d_out,
-                           (bf16_t*)dlogits_ws, temperature, V);
+                           (bf16_t*)dlogits_ws, temperature, t_dev, V);
       else if (al && V % 8 == 0 && V <= 256 * 8 * 8)
         hipLaunchKernelGGL((softmax_bwd_vec_kernel<bf16_t, 8>), dim3((unsigned)BL), dim3(256), 0, stream, (const bf16_t*)probs, (const bf16_t*)d_out,
-                           (bf16_t*)dlogits_ws, temperature, V);
+                           (bf16_t*)dlogits_ws, temperature, t_dev, V);
       else
         hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t>), dim3((unsigned)BL), dim3(256), 0, stream, (const bf16_t*)probs, (const bf16_t*)d_out,
-                           (bf16_t*)dlogits_ws, temperature, V);
+                           (bf16_t*)dlogits_ws, temperature, t_dev, V);
     }
     GIC_CHECK_LAUNCH("softmax_bwd");
   }
@@ -805,6 +813,16 @@ int gic_decoder_forward_tf(const gic_decoder_dims* dims, const gic_decoder_param
 
 void gic_debug_decoder_step(int v) { decoder_step_debug(v); }
 
+// one thread: *dev = v (gic_step_scalars_set; the values travel as a kernel argument)
+__global__ void step_scalars_set_kernel(gic_step_scalars* dev, const gic_step_scalars v) { *dev = v; }
+
+int gic_step_scalars_set(gic_step_scalars* dev, const gic_step_scalars* host_values, void* stream) {
+  GIC_CHECK_ARG(dev && host_values, "step_scalars_set: null argument");
+  hipLaunchKernelGGL(step_scalars_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dev, *host_values);
+  GIC_CHECK_LAUNCH("step_scalars_set");
+  return GIC_OK;
+}
+
 int gic_decoder_fused_rollout_rows(const gic_decoder_dims* dims, int32_t* out) {
   Ctx c;
   GIC_PROPAGATE(check_dims(dims, c));
@@ -881,6 +899,7 @@ int gic_decoder_sample_fwd(const gic_decoder_dims* dims, const gic_decoder_param
   const bool keep = !(opt && opt->no_state);
   GIC_CHECK_ARG(!keep || (st->hout && out), "decoder_sample_fwd: out / state->hout may be NULL only for a stateless roll-out (opts->no_state)");
   GIC_CHECK_ARG(!(opt && opt->force_len && !opt->force_ids), "decoder_sample_fwd: force_len without force_ids");
+  GIC_CHECK_ARG(!(opt && opt->dev_scalars) || (opt->seed_slot >= 0 && opt->seed_slot < GIC_STEP_SEEDS), "decoder_sample_fwd: seed_slot out of range");
   if (opt && opt->resume_from) {
     GIC_CHECK_ARG(opt->force_ids && opt->force_len && opt->host_active_rows && opt->resume_B > 0 && opt->no_state,
                   "decoder_sample_fwd: resumed roll-outs need force_ids, force_len, host_active_rows, resume_B and no_state");
@@ -900,8 +919,9 @@ int gic_decoder_sample_fwd(const gic_decoder_dims* dims, const gic_decoder_param
 int gic_decoder_sample_bwd(const gic_decoder_dims* dims, const gic_decoder_params* P, const gic_decoder_shadow* S,
                            const gic_decoder_state* st, const gic_decoder_bwd_ws* ws, const void* probs,
                            const int64_t* ids, const void* d_out, float temperature, int pretrain,
-                           const gic_decoder_grads* G, int phases, void* stream_) {
+                           const gic_decoder_grads* G, int phases, const gic_step_scalars* dev_scalars, void* stream_) {
   Ctx c;
+  const float* t_dev = dev_scalars ? &dev_scalars->temperature : nullptr;
   GIC_PROPAGATE(check_dims(dims, c));
   GIC_CHECK_ARG(P && S && st && ws && probs && ids && d_out && G, "decoder_sample_bwd: null argument");
   GIC_CHECK_ARG(ws->dlogits && ws->dhout && G->embed && G->w_out && G->b_out && G->features, "decoder_sample_bwd: null buffer");
@@ -911,8 +931,8 @@ int gic_decoder_sample_bwd(const gic_decoder_dims* dims, const gic_decoder_param
   hipStream_t stream = (hipStream_t)stream_;
   GIC_CHECK_ARG(phases >= 1 && phases <= (GIC_DECODER_BWD_ALL | GIC_DECODER_BWD_STATE_GRADS), "decoder_sample_bwd: phases must be a mask of 1 | 2 | 4");
   int s = (c.dt == DT_F32)
-              ? sample_bwd_t<float>(c, P, S, st, ws, probs, ids, d_out, temperature, pretrain, G, phases, stream)
-              : sample_bwd_t<bf16_t>(c, P, S, st, ws, probs, ids, d_out, temperature, pretrain, G, phases, stream);
+              ? sample_bwd_t<float>(c, P, S, st, ws, probs, ids, d_out, temperature, t_dev, pretrain, G, phases, stream)
+              : sample_bwd_t<bf16_t>(c, P, S, st, ws, probs, ids, d_out, temperature, t_dev, pretrain, G, phases, stream);
   GIC_PROPAGATE(s);
   if (phases & GIC_DECODER_BWD_RECURRENT)
     GIC_PROPAGATE(embed_scatter_time((const float*)ws->dxh[0], c.ldx(0), ids, G->embed, c.B, c.L, c.E, c.V, stream));

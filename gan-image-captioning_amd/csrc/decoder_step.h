@@ -49,6 +49,8 @@ struct VocabStepArgs {
   const float* u = nullptr;                  // explicit uniforms [B, V] of this step, or null -> Philox(seed, rng_stream)
   uint64_t seed = 0, rng_stream = 0;
   float temperature = 1.f;
+  const float* t_dev = nullptr;              // non-null: temperature / seed are read from device memory (gic_step_scalars), the values
+  const uint64_t* seed_dev = nullptr;        // above are ignored
   int pretrain = 0;
   void* out = nullptr; long out_stride = 0;  // act: out + b*out_stride + v (e or raw logits); null: ids only
   float* part_m = nullptr; float* part_s = nullptr; int nblk = 0;   // [B][nblk] per-tile max / sum of exp

@@ -469,6 +469,8 @@ __device__ __forceinline__ void vocab_step_body(const VocabStepArgs& a, const in
   // ---- epilogue: lane = batch row b0 + 16 nt + lr, vocabulary entries vq .. vq+3
   const float bia[4] = {bias4[0], bias4[1], bias4[2], bias4[3]};
   const float eps = 1e-10f;                                // generator.py:84
+  const float temperature = a.t_dev ? *a.t_dev : a.temperature;      // (scalar loads; device-resident in the replayed step graph)
+  const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
   float y[2][4];
   bool bok[2];
   int brow[2];
@@ -486,7 +488,7 @@ __device__ __forceinline__ void vocab_step_body(const VocabStepArgs& a, const in
           uu[0] = u4[i][0]; uu[1] = u4[i][1]; uu[2] = u4[i][2]; uu[3] = u4[i][3];
         } else {
           uint32_t r0, r1, r2, r3;
-          Philox::gen4(a.seed, a.rng_stream, (uint64_t)brow[i] * (uint64_t)(V >> 2) + (uint64_t)(vq >> 2), r0, r1, r2, r3);
+          Philox::gen4(seed, a.rng_stream, (uint64_t)brow[i] * (uint64_t)(V >> 2) + (uint64_t)(vq >> 2), r0, r1, r2, r3);
           uu[0] = Philox::u01(r0); uu[1] = Philox::u01(r1); uu[2] = Philox::u01(r2); uu[3] = Philox::u01(r3);
         }
       }
@@ -495,7 +497,7 @@ __device__ __forceinline__ void vocab_step_body(const VocabStepArgs& a, const in
         float o = own[i][r] + bia[r];
         if (!a.pretrain) {
           const float g = FAST ? -__logf(-__logf(uu[r] + eps) + eps) : -logf(-logf(uu[r] + eps) + eps);
-          o = (o + g) * a.temperature;
+          o = (o + g) * temperature;
         }
         y[i][r] = o;
       }

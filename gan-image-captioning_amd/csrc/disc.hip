@@ -548,7 +548,7 @@ int disc_head_fwd(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow
 template <typename TA>
 int disc_fwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S, const gic_disc_state* st,
                const void* inp_soft, long ld_inp, const int64_t* inp_ids, int train, const uint8_t* keep_mask,
-               uint64_t seed, float* logits, hipStream_t stream) {
+               uint64_t seed, const uint64_t* seed_dev, float* logits, hipStream_t stream) {
   // 1. embedding
   if (inp_ids) {
     hipLaunchKernelGGL(disc_emb_gather_kernel, dim3(grid1d(c.rowsBL * c.De)), dim3(256), 0, stream, P->emb, inp_ids, st->emb,
@@ -583,7 +583,7 @@ int disc_fwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
     if (train) {
       g.keep_scale = c.keep_scale(1);        // nn.Dropout(p), discriminator.py:10,30
       g.drop_p = c.drop_p;
-      if (keep_mask) { g.mask = keep_mask; g.ldmask = c.F; } else { g.use_philox = 1; g.seed = seed; g.stream = 0x44495343ull; }
+      if (keep_mask) { g.mask = keep_mask; g.ldmask = c.F; } else { g.use_philox = 1; g.seed = seed; g.seed_dev = seed_dev; g.stream = 0x44495343ull; }
       g.mask_out = st->keep; g.ldmask_out = c.Fp;
     }
     GIC_PROPAGATE(gemm(g, stream));
@@ -595,10 +595,11 @@ int disc_fwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
 // y = sig(h) relu(h) + (1 - sig(h)) x, exactly the EPI_HIGHWAY epilogue incl. its Philox indexing (4 rows per draw).
 template <typename TA>
 __global__ void disc_highway_redrop_kernel(const float* __restrict__ hpre, const TA* __restrict__ pooled,
-                                           const uint8_t* __restrict__ mask, int train, uint64_t seed, float drop_p,
+                                           const uint8_t* __restrict__ mask, int train, uint64_t seed_val, const uint64_t* __restrict__ seed_dev, float drop_p,
                                            float keep_scale, TA* __restrict__ ydrop, uint8_t* __restrict__ keep_out,
                                            long rows, int F, int Fp) {
   const long groups = (rows + 3) / 4;
+  const uint64_t seed = seed_dev ? *seed_dev : seed_val;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups * F; i += (long)gridDim.x * blockDim.x) {
     const long m4 = i / F;
     const int n = (int)(i % F);
@@ -629,10 +630,11 @@ __global__ void disc_highway_redrop_kernel(const float* __restrict__ hpre, const
 
 template <typename TA>
 int disc_fwd_redrop_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S, const gic_disc_state* src,
-                      const gic_disc_state* dst, int train, const uint8_t* keep_mask, uint64_t seed, float* logits, hipStream_t stream) {
+                      const gic_disc_state* dst, int train, const uint8_t* keep_mask, uint64_t seed, const uint64_t* seed_dev, float* logits,
+                      hipStream_t stream) {
   const long groups = (c.rowsBR + 3) / 4;
   hipLaunchKernelGGL((disc_highway_redrop_kernel<TA>), dim3(grid1d(groups * c.F)), dim3(256), 0, stream, (const float*)src->hpre,
-                     (const TA*)src->pooled, keep_mask, train, seed, c.drop_p, c.keep_scale(train), (TA*)dst->ydrop,
+                     (const TA*)src->pooled, keep_mask, train, seed, seed_dev, c.drop_p, c.keep_scale(train), (TA*)dst->ydrop,
                      train ? dst->keep : nullptr, c.rowsBR, c.F, c.Fp);
   GIC_CHECK_LAUNCH("disc_highway_redrop");
   return disc_head_fwd(c, P, S, dst, logits, stream);
@@ -815,8 +817,10 @@ int gic_disc_prepare(const gic_disc_dims* dims, const gic_disc_params* P, const 
 
 int gic_disc_fwd(const gic_disc_dims* dims, const gic_disc_params* P, const gic_disc_shadow* S, const gic_disc_state* st,
                  const void* inp_soft, int64_t ld_inp, const int64_t* inp_ids, int train, const uint8_t* keep_mask,
-                 uint64_t seed, float* logits, void* stream) {
+                 uint64_t seed, float* logits, const gic_step_scalars* dev_scalars, int seed_slot, void* stream) {
   DCtx c;
+  GIC_CHECK_ARG(!dev_scalars || (seed_slot >= 0 && seed_slot < GIC_STEP_SEEDS), "disc_fwd: seed_slot out of range");
+  const uint64_t* seed_dev = dev_scalars ? &dev_scalars->seed[seed_slot] : nullptr;
   GIC_PROPAGATE(make_ctx(dims, P, nullptr, c));
   GIC_CHECK_ARG(P && S && st && logits, "disc_fwd: null argument");
   GIC_CHECK_ARG((inp_soft != nullptr) != (inp_ids != nullptr), "disc_fwd: pass exactly one of inp_soft / inp_ids");
@@ -825,20 +829,23 @@ int gic_disc_fwd(const gic_disc_dims* dims, const gic_disc_params* P, const gic_
   GIC_CHECK_ARG(st->emb && st->pooled && st->ydrop && st->feat && (!train || (st->keep && st->argmax && st->hpre)), "disc_fwd: null state buffer");
   GIC_CHECK_ARG(P->emb && P->hw_b && P->f2o_b && P->o2l_w && P->o2l_b && S->emb && S->hw_w && S->f2o_w, "disc_fwd: null parameter");
   if (c.dt == DT_F32)
-    return disc_fwd_t<float>(c, P, S, st, inp_soft, ld_inp, inp_ids, train, keep_mask, seed, logits, (hipStream_t)stream);
-  return disc_fwd_t<bf16_t>(c, P, S, st, inp_soft, ld_inp, inp_ids, train, keep_mask, seed, logits, (hipStream_t)stream);
+    return disc_fwd_t<float>(c, P, S, st, inp_soft, ld_inp, inp_ids, train, keep_mask, seed, seed_dev, logits, (hipStream_t)stream);
+  return disc_fwd_t<bf16_t>(c, P, S, st, inp_soft, ld_inp, inp_ids, train, keep_mask, seed, seed_dev, logits, (hipStream_t)stream);
 }
 
 int gic_disc_fwd_redrop(const gic_disc_dims* dims, const gic_disc_params* P, const gic_disc_shadow* S, const gic_disc_state* src,
-                        const gic_disc_state* dst, int train, const uint8_t* keep_mask, uint64_t seed, float* logits, void* stream) {
+                        const gic_disc_state* dst, int train, const uint8_t* keep_mask, uint64_t seed, float* logits,
+                        const gic_step_scalars* dev_scalars, int seed_slot, void* stream) {
   DCtx c;
+  GIC_CHECK_ARG(!dev_scalars || (seed_slot >= 0 && seed_slot < GIC_STEP_SEEDS), "disc_fwd_redrop: seed_slot out of range");
+  const uint64_t* seed_dev = dev_scalars ? &dev_scalars->seed[seed_slot] : nullptr;
   GIC_PROPAGATE(make_ctx(dims, P, nullptr, c));
   GIC_CHECK_ARG(P && S && src && dst && logits, "disc_fwd_redrop: null argument");
   GIC_CHECK_ARG(src->pooled && src->hpre && dst->ydrop && dst->feat && (!train || dst->keep), "disc_fwd_redrop: null state buffer");
   GIC_CHECK_ARG(P->f2o_b && P->o2l_w && P->o2l_b && S->f2o_w, "disc_fwd_redrop: null parameter");
   if (c.dt == DT_F32)
-    return disc_fwd_redrop_t<float>(c, P, S, src, dst, train, keep_mask, seed, logits, (hipStream_t)stream);
-  return disc_fwd_redrop_t<bf16_t>(c, P, S, src, dst, train, keep_mask, seed, logits, (hipStream_t)stream);
+    return disc_fwd_redrop_t<float>(c, P, S, src, dst, train, keep_mask, seed, seed_dev, logits, (hipStream_t)stream);
+  return disc_fwd_redrop_t<bf16_t>(c, P, S, src, dst, train, keep_mask, seed, seed_dev, logits, (hipStream_t)stream);
 }
 
 int gic_disc_bwd(const gic_disc_dims* dims, const gic_disc_params* P, const gic_disc_shadow* S, const gic_disc_state* st,

@@ -35,6 +35,7 @@ struct GemmDesc {
   uint8_t* mask_out = nullptr; long ldmask_out = 0;   // keep mask actually used, written for backward (optional)
   float keep_scale = 1.f;                       // 1/(1-p) in train mode, 1 in eval
   int use_philox = 0; float drop_p = 0.f; uint64_t seed = 0, stream = 0;
+  const uint64_t* seed_dev = nullptr;           // non-null: the Philox seed is read from device memory (gic_step_scalars), `seed` is ignored
   // ---- implicit-GEMM convolution (conv != 0): A(m,k) is gathered from an NHWC activation `A`
   //      [Nimg, cH, cW, cCin] with m = (n, ho, wo) and k = (r, s, c); M = Nimg*cHo*cWo, K = cKH*cKW*cCin;
   //      B = weights [Cout, cKH, cKW, cCin] (k-contiguous).  Out-of-image taps read as zero.

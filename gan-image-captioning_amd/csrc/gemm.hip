@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc d, const int k
       if constexpr (EPI == EPI_HIGHWAY) {
         if (!d.mask && d.use_philox) {       // one Philox4x32 call serves the lane's 4 consecutive rows
           uint32_t r0, r1, r2, r3;
-          Philox::gen4(d.seed, d.stream, (uint64_t)(mb >> 2) * (uint64_t)N + (uint64_t)n, r0, r1, r2, r3);
+          Philox::gen4(d.seed_dev ? *d.seed_dev : d.seed, d.stream, (uint64_t)(mb >> 2) * (uint64_t)N + (uint64_t)n, r0, r1, r2, r3);
           keep4[0] = Philox::u01(r0) >= d.drop_p ? 1.f : 0.f;
           keep4[1] = Philox::u01(r1) >= d.drop_p ? 1.f : 0.f;
           keep4[2] = Philox::u01(r2) >= d.drop_p ? 1.f : 0.f;
@@ -615,9 +615,9 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
       } else {
         voff = (a_ok[i] & kok) ? (unsigned)(a_off[i] + k) * 2u : OOB;
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(sA + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)(sA + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, CONV ? GIC_TRUNK_NT : 0);
       if constexpr (ARES)        // the shortcut tile: same rows and channels of `res`, behind the B tile of the stage
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsR, (lds_void_ptr)(sB + B_BYTES + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsR, (lds_void_ptr)(sB + B_BYTES + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, CONV ? GIC_TRUNK_NT : 0);
     }
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
           keep[0][e] = keep[1][e] = keep[2][e] = keep[3][e] = 1.f;
           if (!d.mask && d.use_philox && n0 + e < N) {
             uint32_t r0, r1, r2, r3;
-            Philox::gen4(d.seed, d.stream, (uint64_t)(m0 >> 2) * (uint64_t)N + (uint64_t)(n0 + e), r0, r1, r2, r3);
+            Philox::gen4(d.seed_dev ? *d.seed_dev : d.seed, d.stream, (uint64_t)(m0 >> 2) * (uint64_t)N + (uint64_t)(n0 + e), r0, r1, r2, r3);
             keep[0][e] = Philox::u01(r0) >= d.drop_p ? 1.f : 0.f;
             keep[1][e] = Philox::u01(r1) >= d.drop_p ? 1.f : 0.f;
             keep[2][e] = Philox::u01(r2) >= d.drop_p ? 1.f : 0.f;
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
         float keep4[4] = {1.f, 1.f, 1.f, 1.f};
         if (!d.mask && d.use_philox) {       // one Philox4x32 call serves the lane's 4 consecutive rows
           uint32_t r0, r1, r2, r3;
-          Philox::gen4(d.seed, d.stream, (uint64_t)(mb >> 2) * (uint64_t)N + (uint64_t)n, r0, r1, r2, r3);
+          Philox::gen4(d.seed_dev ? *d.seed_dev : d.seed, d.stream, (uint64_t)(mb >> 2) * (uint64_t)N + (uint64_t)n, r0, r1, r2, r3);
           keep4[0] = Philox::u01(r0) >= d.drop_p ? 1.f : 0.f;
           keep4[1] = Philox::u01(r1) >= d.drop_p ? 1.f : 0.f;
           keep4[2] = Philox::u01(r2) >= d.drop_p ? 1.f : 0.f;

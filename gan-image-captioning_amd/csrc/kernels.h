@@ -19,7 +19,7 @@ int fill_zero(void* p, size_t bytes, hipStream_t stream);
 int transpose2d(const void* src, void* dst, int dtype, long rows, long cols, hipStream_t stream);
 
 // decoder.hip internals shared with attention.hip
-int decoder_output_bwd(int dt, int B, int L, int V, int H, const void* probs, const void* d_out, float temperature, int pretrain,
+int decoder_output_bwd(int dt, int B, int L, int V, int H, const void* probs, const void* d_out, float temperature, const float* t_dev, int pretrain,
                        void* dlogits_ws, const void* wout, const void* hout, float* dhout, float* d_wout, float* d_bout, hipStream_t stream);
 int embed_scatter_time(const float* dx, long ld, const int64_t* ids, float* d_embed, int B, int L, int E, int V, hipStream_t stream);
 

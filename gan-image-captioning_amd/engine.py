@@ -83,6 +83,23 @@ def _key(params: Sequence[torch.Tensor]):
     return tuple((p.data_ptr(), p._version) for p in params) + (_param_epoch,)
 
 
+class StepScalarsBuffer:
+    """Device-resident gic_step_scalars (gicap.h): the decoder's temperature and the seeds of the step's device noise streams, read
+    by the kernels from device memory so that a captured step graph replays with unchanged launch arguments."""
+
+    def __init__(self, device):
+        self.buf = torch.zeros(C.sizeof(L.StepScalars), dtype=torch.uint8, device=device)
+        self.ptr = self.buf.data_ptr()
+
+    def set(self, temperature: float, seeds) -> None:
+        """Enqueue the update on the current stream (values travel as kernel arguments)."""
+        v = L.StepScalars()
+        v.temperature = float(temperature)
+        for i, sd in enumerate(seeds):
+            v.seed[i] = int(sd) & (2 ** 64 - 1)
+        L.check(L.load().gic_step_scalars_set(self.ptr, C.byref(v), stream_ptr()), "gic_step_scalars_set")
+
+
 # ------------------------------------------------------------------------------------------ generic ops
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, bias=None, accumulate=False, alpha=1.0):
     require_gpu(A, B, Cout)
@@ -313,8 +330,9 @@ class DecoderEngine:
     def sample_fwd(self, params, features: torch.Tensor, Lc: int, temperature: float, pretrain: bool = False,
                    noise_u: Optional[torch.Tensor] = None, seed: int = 0, state=None, out=None, ids=None,
                    states=None, force_ids: Optional[torch.Tensor] = None, force_len: Optional[torch.Tensor] = None,
-                   ids_only: bool = False, resume=None):
-        """``states`` = (h0, c0), each f32 [NL, B, H] (generator.py:55,61).  ``force_ids`` int64 [B, L] (+ ``force_len`` int32 [B]):
+                   ids_only: bool = False, resume=None, dev_scalars=None, seed_slot: int = 0):
+        """``dev_scalars`` (StepScalarsBuffer) / ``seed_slot``: temperature and seed are read from device memory (gicap.h
+        gic_step_scalars; fused step kernels only).  ``states`` = (h0, c0), each f32 [NL, B, H] (generator.py:55,61).  ``force_ids`` int64 [B, L] (+ ``force_len`` int32 [B]):
         trajectory to follow (gicap.h).  ``ids_only``: inference roll-out, returns (None, ids, state) and saves nothing for backward.
         ``resume`` = (state of an earlier call, its batch size, active_rows list[L]): resumed roll-outs (gicap.h,
         gic_decoder_sample_opts.resume_from) -- rows sorted by prefix length, each starting at its prefix from that call's state."""
@@ -339,8 +357,10 @@ class DecoderEngine:
         ids = ids if ids is not None else torch.empty(B, Lc, device=dev, dtype=torch.int64)
         opts = None
         keep = []
-        if states is not None or force_ids is not None or ids_only:
+        if states is not None or force_ids is not None or ids_only or dev_scalars is not None:
             opts = L.DecoderSampleOpts()
+            if dev_scalars is not None:
+                opts.dev_scalars, opts.seed_slot = dev_scalars.ptr, int(seed_slot)
             if states is not None:
                 h0, c0 = (t.detach().to(torch.float32).contiguous() for t in states)
                 if tuple(h0.shape) != (self.NL, B, self.H) or tuple(c0.shape) != (self.NL, B, self.H):
@@ -412,7 +432,7 @@ class DecoderEngine:
         return out, (h_n, c_n)
 
     def sample_bwd(self, params, st, out: torch.Tensor, ids: torch.Tensor, d_out: torch.Tensor, temperature: float,
-                   pretrain: bool = False, ws=None, grads=None, phases: int = 3) -> List[torch.Tensor]:
+                   pretrain: bool = False, ws=None, grads=None, phases: int = 3, dev_scalars=None) -> List[torch.Tensor]:
         """phases: 1 = output layer only (w_out / b_out gradients complete), 2 = recurrent part, 3 = both; | 4 = also the gradient of
         the initial states, read back with ``state_grads(ws)`` (gicap.h)."""
         B, Lc = ids.shape
@@ -432,7 +452,8 @@ class DecoderEngine:
         L.check(L.load().gic_decoder_sample_bwd(
             C.byref(d), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
             C.byref(w), ptr(out), ptr(ids), ptr(d_out), float(temperature), int(bool(pretrain)),
-            C.byref(self._pstruct(grads[:-1], L.DecoderGrads, grads[-1])), int(phases), stream_ptr()), "gic_decoder_sample_bwd")
+            C.byref(self._pstruct(grads[:-1], L.DecoderGrads, grads[-1])), int(phases),
+            dev_scalars.ptr if dev_scalars is not None else None, stream_ptr()), "gic_decoder_sample_bwd")
         return grads
 
     def state_grads(self, ws):
@@ -586,8 +607,9 @@ class DiscEngine:
         return inp
 
     def fwd(self, params, inp_soft: Optional[torch.Tensor], inp_ids: Optional[torch.Tensor], train: bool,
-            keep_mask: Optional[torch.Tensor] = None, seed: int = 0, state=None, logits=None, forward_only: bool = False):
-        """``forward_only`` (eval mode only): nothing is saved for a backward pass (see alloc_state)."""
+            keep_mask: Optional[torch.Tensor] = None, seed: int = 0, state=None, logits=None, forward_only: bool = False,
+            dev_scalars=None, seed_slot: int = 0):
+        """``dev_scalars`` / ``seed_slot``: the dropout seed is read from device memory (gic_step_scalars).  ``forward_only`` (eval mode only): nothing is saved for a backward pass (see alloc_state)."""
         if forward_only and train:
             raise ValueError("forward_only is an eval-mode option: the train-mode forward saves its dropout mask for the backward")
         self.check_params(params)
@@ -610,7 +632,7 @@ class DiscEngine:
         L.check(L.load().gic_disc_fwd(
             C.byref(d), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
             ptr(inp_soft), self.V, ptr(inp_ids), int(bool(train)), ptr(keep_mask), int(seed) & (2 ** 64 - 1), ptr(logits),
-            stream_ptr()), "gic_disc_fwd")
+            dev_scalars.ptr if dev_scalars is not None else None, int(seed_slot), stream_ptr()), "gic_disc_fwd")
         return logits, st
 
     def shared_state(self, src: dict, B: int, Lc: int, dev) -> dict:
@@ -622,7 +644,7 @@ class DiscEngine:
         return st
 
     def fwd_redrop(self, params, src_state: dict, dst_state: dict, train: bool, keep_mask: Optional[torch.Tensor] = None,
-                   seed: int = 0, logits=None):
+                   seed: int = 0, logits=None, dev_scalars=None, seed_slot: int = 0):
         """gic_disc_fwd_redrop: D on the same input as the forward that filled ``src_state``, under another dropout draw."""
         self.check_params(params)
         MR = src_state["pooled"].shape[0]
@@ -639,7 +661,7 @@ class DiscEngine:
         L.check(L.load().gic_disc_fwd_redrop(
             C.byref(d), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(src_state)),
             C.byref(self._state_struct(dst_state)), int(bool(train)), ptr(keep_mask), int(seed) & (2 ** 64 - 1), ptr(logits),
-            stream_ptr()), "gic_disc_fwd_redrop")
+            dev_scalars.ptr if dev_scalars is not None else None, int(seed_slot), stream_ptr()), "gic_disc_fwd_redrop")
         return logits, dst_state
 
     def split_state(self, st: dict):

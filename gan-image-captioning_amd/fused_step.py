@@ -34,6 +34,9 @@ class FusedAdvStep:
         self._disc_grads = None
         self.overlap = not os.environ.get("GIC_NO_STREAM_OVERLAP")
         self.trace = None
+        self.use_graph = not (os.environ.get("GIC_NO_STEP_GRAPH") or os.environ.get("GIC_NO_GRAPH"))
+        self._graphs: Dict[tuple, dict] = {}
+        self._warm: set = set()
 
     # grads of the decoder parameters are views into the generator arena (order = Decoder.param_list())
     def _grad_lists(self):
@@ -97,28 +100,53 @@ class FusedAdvStep:
         Independent branches of the step's dependency graph run on side HIP streams behind events:
           D(real) forward          || encoder head + roll-out         (and the NEXT batch's trunk forward under all of it)
           G path (D(gen) input-gradient, decoder / encoder-head backward)  ||  D path (backward real + fake, D's Adam)
-        D's weights are not updated before the G path has finished reading them; both paths join before G's Adam."""
+        D's weights are not updated before the G path has finished reading them; both paths join before G's Adam.
+
+        A training step with device-drawn noise is replayed as six linear hipGraphs from its third call on (``_call_graph``): everything
+        behind the trunk features -- ~110 launches on three streams -- with the per-step scalars (temperature, noise seeds) read from
+        device memory (engine.StepScalarsBuffer); GIC_NO_STEP_GRAPH=1 (or GIC_NO_GRAPH=1) keeps the eager launches.  Returned tensors
+        of a replayed step live in the graphs' memory pools and are overwritten by the next step."""
+        B, L = captions.shape[0], int(max_caption_len)
+        engine.require_gpu(captions, images)
+        if (self.use_graph and train and opt_step and noise_u is None and keep_masks is None and self.reducer is None and self.overlap
+                and self.trace is None):
+            return self._call_graph(images, captions, B, L, next_images, next_train)
+        dev = captions.device
+        main = torch.cuda.current_stream(dev)
+        km = keep_masks if keep_masks is not None else (None, None, None)
+        seeds = [0 if km[i] is not None else SEEDS.next() for i in range(3)]
+        seeds.append(0 if noise_u is not None else SEEDS.next())
+        ev_start = main.record_event()
+        self._mark("start", main)
+        trunk = (lambda: self._take_and_prefetch(images, train, main, ev_start, next_images, next_train)) if self.cgan else None
+        return self._body(self._buffers(B, L, dev), captions, trunk, images, float(self.gen.decoder.temperature), train, noise_u, km, seeds,
+                          None, opt_step, main, ev_start)
+
+    def _take_and_prefetch(self, images, train, main, ev_start, next_images, next_train):
+        """This step's trunk features (the look-ahead pass of the previous step, or a pass now), then the NEXT batch's pass on its stream."""
+        enc = self.gen.encoder
+        trunk_feats = enc.take_trunk(images, train, main)
+        if next_images is not None:          # the prefetched output is a private copy: the next trunk pass may start now
+            enc.prefetch_trunk(next_images, train if next_train is None else next_train, ev_start, mark=self._mark)
+        return trunk_feats
+
+    def _body(self, buf, captions, trunk, images, T, train, noise_u, km, seeds, scal, opt_step, main, ev_start) -> dict:
+        """Everything of the step on `main` and the two side streams.  ``trunk``: callable returning the trunk features (the eager
+        path calls it after D(real) and the weight images are under way) or a tensor (graph path: the static input buffer).
+        ``scal``: StepScalarsBuffer or None (temperature ``T`` / ``seeds`` by value)."""
         a = self.args
         gen, disc = self.gen, self.disc
-        B, L = captions.shape[0], int(max_caption_len)
+        B, L = captions.shape
         dev = captions.device
-        engine.require_gpu(captions, images)
-        buf = self._buffers(B, L, dev)
         gparams = [p.detach() for p in gen.decoder.param_list()]
         dparams = [p.detach() for p in disc.param_list()]
         g_grads, d_grads = self._grad_lists()
-        T = float(gen.decoder.temperature)
         d_train = bool(train)            # dropout active in train mode only (disc.train()/eval(), training.py:215,219)
-        main = torch.cuda.current_stream(dev)
         overlap = self.overlap
         s_real, s_gen = self._streams(dev) if overlap else (main, main)
-        km = keep_masks if keep_masks is not None else (None, None, None)
-        seeds = [0 if km[i] is not None else SEEDS.next() for i in range(3)]
         lg = buf["logits"]
 
         # compute-dtype weight images are refreshed on the side streams, under the encoder
-        ev_start = main.record_event()
-        self._mark("start", main)
         with torch.cuda.stream(s_gen):
             s_gen.wait_event(ev_start)
             self.dec.prepare(gparams)
@@ -134,31 +162,28 @@ class FusedAdvStep:
             else:
                 real_soft = self.den.soft_input(torch.nn.functional.one_hot(captions, self.den.V).float())
                 real_ids = None
-            self.den.fwd(dparams, real_soft, real_ids, d_train, km[0], seeds[0], state=buf["st_real"], logits=lg[0])
+            self.den.fwd(dparams, real_soft, real_ids, d_train, km[0], seeds[0], state=buf["st_real"], logits=lg[0], dev_scalars=scal, seed_slot=0)
             ev_real = s_real.record_event()
             self._mark("D(real) fwd done [s_real]", s_real)
 
         # ---- features (training.py:144-147) and one roll-out (training.py:150)
         if self.cgan:
-            trunk_feats = gen.encoder.take_trunk(images, train, main)
-            if next_images is not None:          # the prefetched output is a private copy: the next trunk pass may start now
-                gen.encoder.prefetch_trunk(next_images, train if next_train is None else next_train, ev_start, mark=self._mark)
+            trunk_feats = trunk() if callable(trunk) else trunk
             feats = gen.encoder.forward_fused(images, train, trunk_feats=trunk_feats)
         else:
             feats = engine.embedding_fwd(gparams[0], buf["ones"])
         self._mark("encoder done", main)
-        seed = 0 if noise_u is not None else SEEDS.next()
         main.wait_event(ev_gprep)
         # (measured: issuing the roll-out from a high-priority stream does not win it CU slots from the look-ahead trunk pass --
         # it finished only after the whole trunk pass -- so it stays on the main stream)
-        probs, ids, dst = self.dec.sample_fwd(gparams, feats, L, T, False, noise_u, seed, state=buf["dec_state"],
-                                              out=buf["probs"], ids=buf["ids"])
+        probs, ids, dst = self.dec.sample_fwd(gparams, feats, L, T, False, noise_u, seeds[3], state=buf["dec_state"],
+                                              out=buf["probs"], ids=buf["ids"], dev_scalars=scal, seed_slot=3)
         self._mark("roll-out done", main)
 
         # ---- D(fake), D(gen) (training.py:163-164): one pass up to the highway layer, two dropout draws + heads
         main.wait_event(ev_dprep)
-        self.den.fwd(dparams, probs, None, d_train, km[1], seeds[1], state=buf["st_fake"], logits=lg[1])
-        self.den.fwd_redrop(dparams, buf["st_fake"], buf["st_gen"], d_train, km[2], seeds[2], logits=lg[2])
+        self.den.fwd(dparams, probs, None, d_train, km[1], seeds[1], state=buf["st_fake"], logits=lg[1], dev_scalars=scal, seed_slot=1)
+        self.den.fwd_redrop(dparams, buf["st_fake"], buf["st_gen"], d_train, km[2], seeds[2], logits=lg[2], dev_scalars=scal, seed_slot=2)
         self._mark("D(fake), D(gen) fwd done", main)
         main.wait_event(ev_real)
         losses, lgrads = engine.gan_losses(a.adv_loss_type, lg[0], lg[1], lg[2], want_grads=train)
@@ -171,7 +196,7 @@ class FusedAdvStep:
         # ---- G path on its stream: g_loss -> D(gen) input grad -> decoder -> encoder head (training.py:169 minus the step)
         with torch.cuda.stream(s_gen):
             s_gen.wait_event(ev_loss)
-            if overlap:
+            if overlap and scal is None:         # (a captured step keeps `lgrads` alive in the graph's own pool)
                 lgrads["dg_out"].record_stream(s_gen)
             if a.adv_loss_type == "rsgan":
                 self.gen_arena.grad.zero_()                        # utils.py:48: g_loss has no path to G
@@ -184,15 +209,15 @@ class FusedAdvStep:
                 early = self._early_bucket() if self.reducer is not None else None
                 if early is None:
                     self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"],
-                                        grads=g_grads + [buf["d_feat"]])
+                                        grads=g_grads + [buf["d_feat"]], dev_scalars=scal)
                 else:
                     # data parallel: the vocabulary projection's gradient (40 % of G's arena) is complete before BPTT starts;
                     # its all-reduce runs under BPTT and the weight-gradient products instead of after them
                     self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"],
-                                        grads=g_grads + [buf["d_feat"]], phases=1)
+                                        grads=g_grads + [buf["d_feat"]], phases=1, dev_scalars=scal)
                     self.reducer.start(self.gen_arena.grad[early[0]:early[1]])
                     self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"],
-                                        grads=g_grads + [buf["d_feat"]], phases=2)
+                                        grads=g_grads + [buf["d_feat"]], phases=2, dev_scalars=scal)
                 if self.cgan:
                     gen.encoder.backward_fused(buf["d_feat"])
                 else:   # features = embed(<S>) broadcast: fold d_features into row 1 of the embedding gradient
@@ -237,6 +262,166 @@ class FusedAdvStep:
             self.gen_opt.step()
         self._mark("optimizers done", main)
         return out
+
+    # ---------------------------------------------------------------- the step as replayed hipGraphs
+    def _graph_key(self, B: int, L: int) -> tuple:
+        a = self.args
+        return (B, L, self.cgan, a.adv_loss_type, int(getattr(a, "real_as_ids", 1)), self.gen_arena.flat.data_ptr(), self.disc_arena.flat.data_ptr(),
+                id(self.gen_opt), id(self.disc_opt), self.gen_opt.lr, self.gen_opt.clip_norm, self.disc_opt.lr, self.disc_opt.clip_norm,
+                self.den.drop_p, bool(self.gen.training), bool(self.disc.training))
+
+    def _segments(self, buf, scal):
+        """The step as LINEAR launch sequences, one per stretch between two cross-stream dependencies: each is captured as its own
+        hipGraph and replayed on its stream, with the events between them recorded / waited on eagerly.  (The whole step as ONE
+        multi-branch graph replays slower than eager launches on this runtime -- 3.49 against 2.67 ms per step, measured, round 3:
+        fork / join nodes inside a graph cost more than the stream events they replace -- while a linear graph replays at the
+        eager rate: the trunk pass has always been one.)  Returns {name: callable}; shared state travels through ``ctx``."""
+        a = self.args
+        gen, disc = self.gen, self.disc
+        caps = buf["caps_in"]
+        B, L = caps.shape
+        lg = buf["logits"]
+        ctx = {}
+        g_grads, d_grads = self._grad_lists()
+        gparams = [p.detach() for p in gen.decoder.param_list()]
+        dparams = [p.detach() for p in disc.param_list()]
+        real_ids = int(getattr(a, "real_as_ids", 1)) != 0
+
+        def d_real():                     # s_real: D's weight images + D(real) forward (training.py:162)
+            self.den.prepare(dparams)
+            if real_ids:
+                ctx["real_soft"], ctx["real_ids"] = None, caps
+            else:
+                ctx["real_soft"] = self.den.soft_input(torch.nn.functional.one_hot(caps, self.den.V).float())
+                ctx["real_ids"] = None
+            self.den.fwd(dparams, ctx["real_soft"], ctx["real_ids"], True, None, 0, state=buf["st_real"], logits=lg[0], dev_scalars=scal, seed_slot=0)
+
+        def rollout():                    # main: G's weight images, features (training.py:144-147), one roll-out (training.py:150)
+            self.dec.prepare(gparams)
+            if self.cgan:
+                ctx["feats"] = gen.encoder.forward_fused(None, True, trunk_feats=buf["trunk_in"])
+            else:
+                ctx["feats"] = engine.embedding_fwd(gparams[0], buf["ones"])
+            ctx["probs"], ctx["ids"], ctx["dst"] = self.dec.sample_fwd(gparams, ctx["feats"], L, 0.0, False, None, 0, state=buf["dec_state"],
+                                                                      out=buf["probs"], ids=buf["ids"], dev_scalars=scal, seed_slot=3)
+
+        def d_fake():                     # main, behind D(real): D(fake), D(gen) (training.py:163-164), losses
+            self.den.fwd(dparams, ctx["probs"], None, True, None, 0, state=buf["st_fake"], logits=lg[1], dev_scalars=scal, seed_slot=1)
+            self.den.fwd_redrop(dparams, buf["st_fake"], buf["st_gen"], True, None, 0, logits=lg[2], dev_scalars=scal, seed_slot=2)
+            ctx["losses"], ctx["lgrads"] = engine.gan_losses(a.adv_loss_type, lg[0], lg[1], lg[2], want_grads=True)
+
+        def g_dgen():                     # s_gen, behind the losses: g_loss -> D(gen) input gradient (reads D's weights)
+            if a.adv_loss_type == "rsgan":
+                self.gen_arena.grad.zero_()                        # utils.py:48: g_loss has no path to G
+            else:
+                self.den.bwd(dparams, buf["st_gen"], ctx["probs"], None, True, ctx["lgrads"]["dg_out"], False, True,
+                             ws=buf["disc_ws_gen"], d_inp=buf["d_probs"])
+
+        def g_bwd():                      # s_gen: decoder BPTT + weight gradients, encoder head (training.py:169 minus the step)
+            if a.adv_loss_type == "rsgan":
+                return
+            self.dec.sample_bwd(gparams, ctx["dst"], ctx["probs"], ctx["ids"], buf["d_probs"], 0.0, False, ws=buf["dec_ws"],
+                                grads=g_grads + [buf["d_feat"]], dev_scalars=scal)
+            if self.cgan:
+                gen.encoder.backward_fused(buf["d_feat"])
+            else:
+                engine.embedding_bwd(buf["d_feat"], buf["ones"], self.dec.V, d_weight=g_grads[0], zero_first=False)
+
+        def d_bwd():                      # main, behind the losses: d_loss -> D parameters (training.py:168)
+            self.disc_arena.grad.zero_()
+            if real_ids:
+                self.den.bwd(dparams, buf["st_rf"], ctx["probs"], ctx["real_ids"], True, ctx["lgrads"]["dd_real_fake"], True, False,
+                             grads=d_grads, accumulate=True, ws=buf["disc_ws"])
+            else:
+                half_ws = {k: v[:v.shape[0] // 2] for k, v in buf["disc_ws"].items()}
+                self.den.bwd(dparams, buf["st_real"], ctx["real_soft"], None, True, ctx["lgrads"]["dd_real"], True, False,
+                             grads=d_grads, accumulate=True, ws=half_ws)
+                self.den.bwd(dparams, buf["st_fake"], ctx["probs"], None, True, ctx["lgrads"]["dd_fake"], True, False,
+                             grads=d_grads, accumulate=True, ws=half_ws)
+
+        return ctx, {"d_real": d_real, "rollout": rollout, "d_fake": d_fake, "g_dgen": g_dgen, "g_bwd": g_bwd, "d_bwd": d_bwd,
+                     "d_opt": self.disc_opt.step, "g_opt": self.gen_opt.step}
+
+    def _call_graph(self, images, captions, B: int, L: int, next_images, next_train) -> dict:
+        """Call 1 with a given key runs the segments eagerly (lazy code-object loads, LDS grants and buffer allocation are not
+        capturable), call 2 captures each of them as it goes, later calls replay them.  Outside the graphs: the trunk look-ahead
+        hand-over (its own replayed graph on its own stream), the copies of this batch's captions / trunk features into the step's
+        static input buffers, the one-thread launch that writes temperature and seeds into device memory, and the stream events."""
+        dev = captions.device
+        main = torch.cuda.current_stream(dev)
+        buf = self._buffers(B, L, dev)
+        if "caps_in" not in buf:
+            buf["caps_in"] = torch.empty(B, L, device=dev, dtype=torch.int64)
+            buf["scal"] = engine.StepScalarsBuffer(dev)
+            if self.cgan:
+                buf["trunk_in"] = torch.empty(B, self.gen.encoder.resnet.out_features, device=dev, dtype=self.dec.act)
+        scal = buf["scal"]
+        key = self._graph_key(B, L)
+        g = self._graphs.get(key)
+        if g is None:
+            mode = "capture" if key in self._warm else "eager"
+            self._warm.add(key)
+            if mode == "capture":
+                self._graphs.clear()             # at most one live set of step graphs (stale pointers never replay); dies here, outside capture
+                self.dec._shadow_key = self.den._shadow_key = None      # the weight-image refresh is part of every replay
+            ctx, seg = self._segments(buf, scal)
+            g = {"ctx": ctx, "seg": seg, "graphs": {}, "mode": mode}
+            if mode == "capture":
+                self._graphs[key] = g
+        s_real, s_gen = self._streams(dev)
+
+        def run(name, stream):
+            """One segment on ``stream`` (already made current by the caller): replay, or capture-then-replay, or eager."""
+            gr = g["graphs"].get(name)
+            if gr is not None:
+                gr.replay()
+            elif g["mode"] == "capture":
+                gr = torch.cuda.CUDAGraph()
+                with engine.capture_guard(), torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                    g["seg"][name]()
+                g["graphs"][name] = gr
+                gr.replay()
+            else:
+                g["seg"][name]()
+
+        try:
+            buf["caps_in"].copy_(captions)
+            scal.set(float(self.gen.decoder.temperature), [SEEDS.next() for _ in range(4)])
+            ev_start = main.record_event()
+            with torch.cuda.stream(s_real):
+                s_real.wait_event(ev_start)
+                run("d_real", s_real)
+                ev_real = s_real.record_event()
+            if self.cgan:
+                buf["trunk_in"].copy_(self._take_and_prefetch(images, True, main, ev_start, next_images, next_train))
+            run("rollout", main)
+            main.wait_event(ev_real)
+            run("d_fake", main)
+            ev_loss = main.record_event()
+            with torch.cuda.stream(s_gen):
+                s_gen.wait_event(ev_loss)
+                run("g_dgen", s_gen)
+                ev_dgen = s_gen.record_event()       # D's weights are free to change from here on
+                run("g_bwd", s_gen)
+                ev_g = s_gen.record_event()
+            run("d_bwd", main)
+            main.wait_event(ev_dgen)
+            g["seg"]["d_opt"]()                      # two launches each: eager (D's clip + Adam runs under the rest of the G path)
+            main.wait_event(ev_g)
+            g["seg"]["g_opt"]()
+        except Exception as exc:
+            if g["mode"] != "capture":
+                raise
+            import warnings                          # capture refused: eager launches from here on (same kernels, same results)
+            warnings.warn(f"hipGraph capture of the train step failed ({exc}); falling back to eager launches")
+            self.use_graph = False
+            self._graphs.clear()
+            torch.cuda.synchronize()
+            self.dec._shadow_key = self.den._shadow_key = None
+            return self(images, captions, L, True, next_images=next_images, next_train=next_train)
+        g["mode"] = "replay" if g["mode"] == "capture" else g["mode"]
+        ctx = g["ctx"]
+        return {"losses": ctx["losses"], "ids": ctx["ids"], "probs": ctx["probs"], "logits": buf["logits"]}
 
     def bind_optimizers(self, gen_opt, disc_opt) -> "FusedAdvStep":
         self.gen_opt, self.disc_opt = gen_opt, disc_opt

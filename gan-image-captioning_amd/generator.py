@@ -34,6 +34,10 @@ class _SeedStream:
 
     rank = 0        # data-parallel rank (set by GANInstructor): replicas draw DIFFERENT Gumbel noise / dropout masks
 
+    def reset(self, n: int = 0) -> None:
+        """Restart the counter (tests: two runs that must draw the same device noise)."""
+        self._n = int(n)
+
     def next(self) -> int:
         self._n += 1
         return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._n * 0xD1B54A32D192ED03

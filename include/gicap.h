@@ -48,6 +48,22 @@ int gic_abi_version(void);
 const char* gic_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Per-step scalars resident in DEVICE memory (ABI v3).  The values that change from one train step to the next -- the decoder's
+ * temperature (src/training.py:183, 190-191: updated after every batch) and the seeds of the device noise streams (Gumbel uniforms,
+ * src/generator.py:86-90; the three dropout draws, src/discriminator.py:58) -- can be read by the kernels from this struct instead
+ * of being passed by value: the launch arguments of a whole step then never change, which is what lets the step be ONE replayed
+ * hipGraph.  Entry points that take a `dev_scalars` pointer ignore their by-value `temperature` / `seed` when it is non-NULL and
+ * read dev_scalars->temperature / dev_scalars->seed[seed_slot] on the device.  gic_step_scalars_set enqueues a one-thread kernel
+ * that writes *dev from the host values (captured by value at the call: no pinned staging buffer to keep alive). */
+#define GIC_STEP_SEEDS 6
+typedef struct gic_step_scalars {
+  float temperature;
+  uint32_t reserved;
+  uint64_t seed[GIC_STEP_SEEDS];
+} gic_step_scalars;
+int gic_step_scalars_set(gic_step_scalars* dev, const gic_step_scalars* host_values, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Generic dense contraction (used by the tests and by every entry point below).
  *   C[m,n] = alpha * sum_k A(m,k) B(n,k) + bias[n]  (+ C if accumulate)
  *   A(m,k) = a_kc ? A[m*lda+k] : A[k*lda+m];  B(n,k) = b_kc ? B[n*ldb+k] : B[k*ldb+n]
@@ -148,6 +164,10 @@ typedef struct gic_decoder_sample_opts {
   const struct gic_decoder_state* resume_from;
   int32_t resume_B;
   const int32_t* host_active_rows;
+  /* device-resident temperature and Philox seed (gic_step_scalars above; fused step kernels only: GIC_STATUS_UNSUPPORTED on the
+   * generic-product path) */
+  const gic_step_scalars* dev_scalars;
+  int32_t seed_slot;
 } gic_decoder_sample_opts;
 
 /* features [B,E] f32.  noise_u: explicit U[0,1) draws [L,B,V] f32 (generator.py:86-90 order) or NULL to
@@ -197,7 +217,7 @@ int gic_decoder_sample_bwd(const gic_decoder_dims* dims, const gic_decoder_param
                            const gic_decoder_shadow* shadow, const gic_decoder_state* state,
                            const gic_decoder_bwd_ws* ws, const void* probs, const int64_t* ids,
                            const void* d_out, float temperature, int pretrain,
-                           const gic_decoder_grads* grads, int phases, void* stream);
+                           const gic_decoder_grads* grads, int phases, const gic_step_scalars* dev_scalars, void* stream);
 
 /* nn.Embedding used as a callable (training.py:68,147): out[i,:] = weight[ids[i],:] and its scatter-add. */
 int gic_embedding_fwd(const float* weight, const int64_t* ids, float* out, int64_t n, int32_t V, int32_t E, void* stream);
@@ -343,12 +363,14 @@ int gic_disc_prepare(const gic_disc_dims* dims, const gic_disc_params* params, c
 
 /* Exactly one of inp_soft (act [B*L, V], row stride ld_inp, rows in (b,l) order) and inp_ids (int64 [B,L];
  * the one-hot of training.py:158 evaluated as a gather) is non-NULL.
- * train != 0: dropout(dims->drop_p) with keep_mask (uint8 0/1 [B*R,F], row stride F) or, if NULL, Philox(seed).
+ * train != 0: dropout(dims->drop_p) with keep_mask (uint8 0/1 [B*R,F], row stride F) or, if NULL, Philox(seed) -- the seed read
+ * from dev_scalars->seed[seed_slot] on the device when dev_scalars != NULL (gic_step_scalars).
  * train == 0 with state->argmax == NULL and / or state->hpre == NULL: a forward that no backward follows (reward evaluation of
  * the SeqGAN-style step): those buffers are not written.  logits: f32 [B*R]. */
 int gic_disc_fwd(const gic_disc_dims* dims, const gic_disc_params* params, const gic_disc_shadow* shadow,
                  const gic_disc_state* state, const void* inp_soft, int64_t ld_inp, const int64_t* inp_ids,
-                 int train, const uint8_t* keep_mask, uint64_t seed, float* logits, void* stream);
+                 int train, const uint8_t* keep_mask, uint64_t seed, float* logits, const gic_step_scalars* dev_scalars,
+                 int seed_slot, void* stream);
 
 /* A second forward on the SAME input as the pass that filled `src` (training.py:163-164 run D twice on gen_captions: only
  * the dropout draw differs): reuses src's pooled features and highway pre-activation, applies a fresh dropout mask
@@ -356,7 +378,7 @@ int gic_disc_fwd(const gic_disc_dims* dims, const gic_disc_params* params, const
  * the backward pass of this forward, dst->emb / pooled / argmax / hpre must alias src's buffers. */
 int gic_disc_fwd_redrop(const gic_disc_dims* dims, const gic_disc_params* params, const gic_disc_shadow* shadow,
                         const gic_disc_state* src, const gic_disc_state* dst, int train, const uint8_t* keep_mask,
-                        uint64_t seed, float* logits, void* stream);
+                        uint64_t seed, float* logits, const gic_step_scalars* dev_scalars, int seed_slot, void* stream);
 
 /* d_logits f32 [B*R].  grads may be NULL (no parameter gradients wanted: the generator's path,
  * training.py:169).  d_inp: act [B*L, V] (row stride ld_dinp) or NULL.

@@ -77,7 +77,14 @@ def make_trunk_params(arch: str, gen: torch.Generator, prefix: str = "encoder.re
     return p
 
 
-def _bn(x, tp, name, training, running, stats_out):
+def _r16(x: torch.Tensor) -> torch.Tensor:
+    """Round to bfloat16 and back (what storing a tensor in the bf16 compute dtype does to it)."""
+    return x.bfloat16().float()
+
+
+def _bn(x, tp, name, training, running, stats_out, x_stored=None):
+    """x: the convolution output the statistics are taken from (f32 accumulators); x_stored: the tensor the affine map is applied to
+    (the same, or its bf16-rounded copy in the storage-emulating mode)."""
     g, b = tp[name + ".weight"], tp[name + ".bias"]
     if training:
         mean = x.mean((0, 2, 3))
@@ -91,24 +98,33 @@ def _bn(x, tp, name, training, running, stats_out):
     else:
         mean, var = running[name + ".running_mean"], running[name + ".running_var"]
     scale = g / torch.sqrt(var + BN_EPS)
-    return x * scale[None, :, None, None] + (b - mean * scale)[None, :, None, None]
+    xs = x if x_stored is None else x_stored
+    return xs * scale[None, :, None, None] + (b - mean * scale)[None, :, None, None]
 
 
 def trunk_forward(tp: Dict[str, torch.Tensor], images: torch.Tensor, arch: str, training: bool = True,
                   running: Optional[Dict[str, torch.Tensor]] = None, prefix: str = "encoder.resnet.",
-                  stats_out: Optional[dict] = None, taps: Optional[dict] = None) -> torch.Tensor:
-    """images [N,3,S,S] -> [N, out_features] (global average pool squeezed)."""
+                  stats_out: Optional[dict] = None, taps: Optional[dict] = None, emulate_bf16: bool = False) -> torch.Tensor:
+    """images [N,3,S,S] -> [N, out_features] (global average pool squeezed).
+
+    ``emulate_bf16``: the same network with every tensor that the bf16 compute mode STORES rounded to bfloat16 at the point where it
+    is stored -- the packed image, the convolution weights, every raw convolution output (the BatchNorm statistics are still taken
+    from the f32 accumulators, as the kernels' epilogues do), every normalised + ReLU'd activation fed to the next convolution, every
+    block output, the pooled feature -- and everything else (products, accumulation, the affine maps, the residual sums) in f32.  It
+    separates what bf16 STORAGE does to this network (a property of the data: a pre-BatchNorm tensor whose per-channel |mean| is
+    many times its spread loses that factor in relative precision when the mean is subtracted) from what the kernels do."""
     kind, counts, widths, exp = ARCHS[arch]
     P = prefix
+    r = _r16 if emulate_bf16 else (lambda t: t)
 
     def conv(x, name, stride, pad):
-        return F.conv2d(x, tp[P + name + ".weight"], None, stride, pad)
+        return F.conv2d(x, r(tp[P + name + ".weight"]), None, stride, pad)
 
-    def bn(x, name):
-        return _bn(x, tp, P + name, training, running, stats_out)
+    def bn(y, name):
+        return _bn(y, tp, P + name, training, running, stats_out, x_stored=r(y) if emulate_bf16 else None)
 
-    x = torch.relu(bn(conv(images, "0", 2, 3), "1"))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = torch.relu(bn(conv(r(images), "0", 2, 3), "1"))
+    x = r(F.max_pool2d(x, 3, 2, 1))
     if taps is not None:
         taps["stem"] = x
     cin = 64
@@ -119,19 +135,19 @@ def trunk_forward(tp: Dict[str, torch.Tensor], images: torch.Tensor, arch: str, 
             cout = w * exp
             idt = x
             if kind == "basic":
-                y = torch.relu(bn(conv(x, p + "conv1", stride, 1), p + "bn1"))
+                y = r(torch.relu(bn(conv(x, p + "conv1", stride, 1), p + "bn1")))
                 y = bn(conv(y, p + "conv2", 1, 1), p + "bn2")
             else:
-                y = torch.relu(bn(conv(x, p + "conv1", 1, 0), p + "bn1"))
-                y = torch.relu(bn(conv(y, p + "conv2", stride, 1), p + "bn2"))
+                y = r(torch.relu(bn(conv(x, p + "conv1", 1, 0), p + "bn1")))
+                y = r(torch.relu(bn(conv(y, p + "conv2", stride, 1), p + "bn2")))
                 y = bn(conv(y, p + "conv3", 1, 0), p + "bn3")
             if stride != 1 or cin != cout:
                 idt = bn(conv(x, p + "downsample.0", stride, 0), p + "downsample.1")
-            x = torch.relu(y + idt)
+            x = r(torch.relu(y + idt))
             cin = cout
         if taps is not None:
             taps[f"stage{si}"] = x
-    return x.mean((2, 3))
+    return r(x.mean((2, 3)))
 
 
 def macs(arch: str, S: int) -> int:

@@ -48,7 +48,8 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(_lib.DecoderParams) == (3 + 4 * _lib.MAX_LAYERS) * P
     assert ctypes.sizeof(_lib.DecoderGrads) == (4 + 4 * _lib.MAX_LAYERS) * P
     assert ctypes.sizeof(_lib.DecoderState) == (4 + 3 * _lib.MAX_LAYERS) * P
-    assert ctypes.sizeof(_lib.DecoderSampleOpts) == 8 * P          # 4 pointers, int32 (padded), pointer, int32 (padded), pointer
+    assert ctypes.sizeof(_lib.DecoderSampleOpts) == 10 * P         # 4 pointers, int32 (padded), pointer, int32 (padded), 2 pointers, int32 (padded)
+    assert ctypes.sizeof(_lib.StepScalars) == 8 + 8 * _lib.STEP_SEEDS
     assert ctypes.sizeof(_lib.DiscDims) == (6 + 2 * _lib.MAX_CONVS + 3) * 4 + 4       # + float drop_p
     assert ctypes.sizeof(_lib.DiscParams) == (7 + 2 * _lib.MAX_CONVS) * P
 

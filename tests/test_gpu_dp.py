@@ -71,8 +71,8 @@ def test_two_ranks_over_rccl_reproduce_the_single_process_step(tmp_path):
 def test_one_rank_rccl_communicator_drives_the_device_branch(tmp_path):
     """SURVEY 8(e) on a one-GPU box: a 1-rank "nccl" (= RCCL) process group and GradReducer(force=True) execute the device branch --
     side-stream ReduceOp.AVG behind an event, start / wait / wait_all -- and FusedAdvStep with that reducer attached (early bucket of
-    G's arena under BPTT, D's Adam gated on its own collective, the rest of G's arena) reproduces the reducer-less fused step BIT FOR
-    BIT in fp32 over two optimizer steps (an average over one rank is the identity)."""
+    G's arena under BPTT, D's Adam gated on its own collective, the rest of G's arena) reproduces the reducer-less fused step in fp32 over two
+    optimizer steps (an average over one rank is the identity: the raw buffers come back bit for bit)."""
     worker = os.path.join(ROOT, "tests", "dp_rccl1_worker.py")
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port())
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GIC_DIST_BACKEND"):
@@ -83,6 +83,10 @@ def test_one_rank_rccl_communicator_drives_the_device_branch(tmp_path):
     res = torch.load(out)
     assert res["backend"] == "nccl" and res["collectives"] >= 2 * 3 + 3, res["collectives"]      # per step: early bucket, D, 1-2 G spans
     assert res["raw_identity"] and res["pending_after_wait_all"] == 0
-    assert torch.equal(res["plain"]["losses"], res["dp"]["losses"])
-    assert torch.equal(res["plain"]["gen"], res["dp"]["gen"]) and torch.equal(res["plain"]["disc"], res["dp"]["disc"])
-    assert torch.equal(res["plain"]["ids"], res["dp"]["ids"])
+    # (the step is not bit-reproducible run to run: D's weight gradients, the column sums and the embedding scatter add with f32
+    # atomics; the tolerances are those of the two-rank test above, the first step's losses -- no atomics upstream -- are exact)
+    assert torch.equal(res["plain"]["losses"][0], res["dp"]["losses"][0])
+    torch.testing.assert_close(res["plain"]["losses"], res["dp"]["losses"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(res["plain"]["disc"], res["dp"]["disc"], rtol=1e-4, atol=2e-6)
+    torch.testing.assert_close(res["plain"]["gen"], res["dp"]["gen"], rtol=1e-4, atol=2e-6)
+    assert float((res["plain"]["ids"] == res["dp"]["ids"]).float().mean()) >= 0.98

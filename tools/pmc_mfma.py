@@ -7,13 +7,15 @@
 util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs): SQ_VALU_MFMA_BUSY_CYCLES sums, over every SIMD, the
 cycles its matrix pipe was busy (MI355X_MICROARCH.md: "counts cycles", 16 per v_mfma_f32_16x16x32_bf16); GRBM_GUI_ACTIVE is reported
 summed over the 8 XCDs, so /8 = the dispatch's duration in shader cycles."""
-import csv, json, sys
+import csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_common import is_trunk_conv
 acc = {}
 with open(sys.argv[1]) as fh:
     for row in csv.DictReader(fh):
         name = row["Kernel_Name"]
         # the trunk's convolution kernels: tile8 (implicit GEMM), the patch-resident 3x3, the streaming and the panel-resident 1x1 kernels
-        conv = ("tile8_kernel" in name and "Lb1E" in name) or any(k in name for k in ("conv3x3_patch_kernel", "conv1x1_stream_kernel", "conv1x1_panel_kernel", "conv_stem_kernel"))
+        conv = is_trunk_conv(name)
         key = "conv" if conv else ("bn_act" if "bn_act_kernel" in name else None)
         if key is None:
             continue

@@ -6,7 +6,9 @@
 
 bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: counters are in KB; gfx950 FETCH_SIZE reports half of a wide
 coalesced read)."""
-import csv, json, sys
+import csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_common import TRUNK_CONV_LAUNCHES, is_trunk_conv
 def per_kernel(path, counter):
     acc = {}
     with open(path) as fh:
@@ -14,9 +16,7 @@ def per_kernel(path, counter):
             if row.get("Counter_Name") != counter:
                 continue
             name = row["Kernel_Name"]
-            key = "conv" if ("tile8_kernel" in name or any(k in name for k in ("conv3x3_patch_kernel", "conv1x1_stream_kernel", "conv1x1_panel_kernel", "conv_stem_kernel"))
-                             or ("gemm_kernel" in name and "Lb1ELb1ELi" in name and "ELi2ELb1E" in name)) else \
-                  "bn_act" if "bn_act_kernel" in name else None
+            key = "conv" if is_trunk_conv(name) else "bn_act" if "bn_act_kernel" in name else None
             if key is None:
                 continue
             a = acc.setdefault(key, [0, 0.0])
@@ -30,6 +30,9 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
 for key, label in (("conv", "conv_bnstats"), ("bn_act", "bn_act")):
     if key in f and key in w:
         fk, wk = f[key][1] / f[key][0], w[key][1] / w[key][0]
+        if key == "conv" and (f[key][0] % TRUNK_CONV_LAUNCHES or w[key][0] % TRUNK_CONV_LAUNCHES):
+            raise SystemExit(f"conv launches profiled ({f[key][0]} / {w[key][0]}) are not a whole number of {TRUNK_CONV_LAUNCHES}-convolution trunk passes: "
+                             "the kernel-name filter has drifted from the kernels")
         out[label] = {"launches_profiled": f[key][0], "fetch_kb_per_launch": round(fk, 1), "write_kb_per_launch": round(wk, 1),
                       "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
 print(json.dumps(out, indent=1))
