@@ -57,7 +57,10 @@ def parse():
                         "cfg5: SeqGAN policy gradient + 16 Monte-Carlo roll-outs per prefix, 32 captions/GPU (BASELINE configs[3], [4]: "
                         "global batch 256 on 8 GPUs)")
     p.add_argument("--mc-rollouts", type=int, default=16)
-    return p.parse_args()
+    a = p.parse_args()
+    if a.batch is None:                        # BASELINE configs[1..2]: 64 per GPU; configs[3], [4]: global batch 256 over 8 GPUs
+        a.batch = CFG2["B"] if a.workload == "cfg2" else 32
+    return a
 
 
 def encoder_available() -> bool:
@@ -184,7 +187,8 @@ def usable_cores() -> int:
 def cpu_baseline(a, cgan):
     """The CPU oracle on a bounded sample of the same workload: `cpu_steps` full steps at the same batch, median; with the
     encoder in the step (the headline workload) and without it (the part the reference itself owns: torchvision's trunk is not in
-    the reference tree)."""
+    the reference tree).  cfg4 / cfg5 (no reference counterpart): the build-owned oracles of the same steps, fewer
+    timed steps (they are not the driver's default; one cfg5 step with 16 roll-outs per prefix is ~2 minutes of CPU work)."""
     from oracle import cpu_step as O
     # BASELINE.md section 2 asks for all host cores; what this process may actually USE is the smaller of its affinity mask and its
     # cgroup CPU quota (a one-GPU box hands out a 16-core share of a many-core host: 128 threads on that share ran 100x slower)
@@ -198,31 +202,58 @@ def cpu_baseline(a, cgan):
     if cgan:
         from oracle import cpu_encoder as OE
         feat_dim = OE.out_features(a.encoder)
-    gp = O.make_gen_params(V, CFG2["E"], CFG2["H"], CFG2["NL"], g, trunk_feat_dim=feat_dim)
     dp = O.make_disc_params(V, g)
     caps = O.make_captions(B, L, V, g)
-    us, masks = O.make_noise(B, L, V, 900, 64, g)
     gopt, dopt = O.AdamState(1e-4), O.AdamState(1e-4)
     if cgan:
         tp = OE.make_trunk_params(a.encoder, g)
         images = torch.randn(B, 3, CFG2["S"], CFG2["S"], generator=g)
+    n_timed = a.cpu_steps
+    if a.workload == "cfg4":
+        from oracle import cpu_attention as OA
+        n_timed = min(a.cpu_steps, 5)
+        gp = OA.make_attn_params(V, CFG2["E"], CFG2["H"], feat_dim, 512, g)
+        gp.update({k: v for k, v in O.make_gen_params(8, CFG2["E"], 8, 1, g, trunk_feat_dim=feat_dim).items() if k.startswith("encoder.")})
+        us, masks = O.make_noise(B, L, V, 900, 64, g)
+    elif a.workload == "cfg5":
+        from oracle import cpu_seqgan as OS
+        n_timed = 1
+        gp = O.make_gen_params(V, CFG2["E"], CFG2["H"], CFG2["NL"], g, trunk_feat_dim=feat_dim)
+        us = [torch.empty(B, V).uniform_(0, 1, generator=g) for _ in range(L)]
+        masks = [torch.empty(B * 64, 900).bernoulli_(0.8, generator=g) for _ in range(2)]
+    else:
+        gp = O.make_gen_params(V, CFG2["E"], CFG2["H"], CFG2["NL"], g, trunk_feat_dim=feat_dim)
+        us, masks = O.make_noise(B, L, V, 900, 64, g)
     times, times_noenc = [], []
-    for i in range(1 + a.cpu_steps):
+    for i in range((0 if a.workload == "cfg5" else 1) + n_timed):
         log(f"cpu_baseline step {i}")
         t0 = time.perf_counter()
+        taps = {}
         if cgan:
             with torch.no_grad():
-                trunk_feat = OE.trunk_forward(tp, images, a.encoder)
+                trunk_feat = OE.trunk_forward(tp, images, a.encoder, taps=taps)
         t1 = time.perf_counter()
-        O.adv_step(gp, dp, caps, us, masks, 1.5, "standard", 5.0, gopt, dopt, trunk_feat=trunk_feat)
+        if a.workload == "cfg4":
+            fmap = taps["stage3"].permute(0, 2, 3, 1).reshape(B, -1, feat_dim)
+            OA.attn_adv_step(gp, dp, caps, us, masks, 1.5, trunk_feat, fmap, gen_opt=gopt, disc_opt=dopt)
+        elif a.workload == "cfg5":
+            umc = torch.empty(L, (L - 1) * a.mc_rollouts * B, V).uniform_(0, 1, generator=g)      # (drawing it is not timed)
+            t0 += time.perf_counter() - t1
+            t1 = time.perf_counter()
+            OS.seqgan_step(gp, dp, caps, us, umc, a.mc_rollouts, masks, 5.0, gopt, dopt, trunk_feat=trunk_feat)
+        else:
+            O.adv_step(gp, dp, caps, us, masks, 1.5, "standard", 5.0, gopt, dopt, trunk_feat=trunk_feat)
         t2 = time.perf_counter()
         times.append(t2 - t0)
         times_noenc.append(t2 - t1)
-    t = statistics.median(times[1:])
-    tn = statistics.median(times_noenc[1:])
+    first = 0 if a.workload == "cfg5" else 1
+    t = statistics.median(times[first:])
+    tn = statistics.median(times_noenc[first:])
+    oracle_name = {"cfg2": "oracle/cpu_step.py", "cfg4": "oracle/cpu_attention.py (attn_adv_step; no reference counterpart)",
+                   "cfg5": "oracle/cpu_seqgan.py (no reference counterpart)"}[a.workload]
     out = {"value": round(B / t, 2), "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"median of {a.cpu_steps} full steps (after 1 warm-up) of the same batch={B} workload, fp32, oracle/cpu_step.py"
-                     + (" + oracle/cpu_encoder.py trunk" if cgan else ""),
+           "sample": f"median of {n_timed} full step(s)" + (" (after 1 warm-up)" if first else " (no warm-up)")
+                     + f" of the same batch={B} workload, fp32, {oracle_name}" + (" + oracle/cpu_encoder.py trunk" if cgan else ""),
            "ms_per_step": round(t * 1e3, 1)}
     if cgan:
         out["without_encoder"] = {"value": round(B / tn, 2), "ms_per_step": round(tn * 1e3, 1),
@@ -250,8 +281,6 @@ def self_launch(a) -> int:
 
 def main():
     a = parse()
-    if a.batch is None:                        # BASELINE configs[1..2]: 64 per GPU; configs[3], [4]: global batch 256 over 8 GPUs
-        a.batch = CFG2["B"] if a.workload == "cfg2" else 32
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         raise SystemExit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -317,7 +346,7 @@ def main():
         # the in-step measurement runs train steps: only without data parallelism (the other ranks have left; a step would wait for
         # them in its all-reduce) -- with N > 1 the line carries the isolated replay of rank 0
         out["roofline"] = roofline_probe(inst, args, cgan, step if (a.workload != "cfg4" and world == 1) else None)
-    if world == 1 and not a.no_cpu_baseline and a.workload == "cfg2":
+    if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, cgan)
     print(json.dumps(out), flush=True)
 

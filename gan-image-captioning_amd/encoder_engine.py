@@ -113,7 +113,7 @@ class TrunkPlan:
 
     # ---------------------------------------------------------------- weights (frozen: packed once per version)
     def _pack_weights(self, dev) -> None:
-        key = tuple((s.conv.weight.data_ptr(), s.conv.weight._version) for s in self.steps)
+        key = (self.trunk._ptr_epoch, tuple(s.conv.weight._version for s in self.steps))      # (see ResNetTrunk._ptr_epoch)
         if key == self._wkey:
             return
         lib = L.load()
@@ -187,7 +187,7 @@ class TrunkPlan:
     def _running_table(self, b: dict, dev) -> None:
         """Device table for the one-launch running-statistics update.  It bakes in the BatchNorm buffers' addresses, so it is
         rebuilt whenever they move (module .to() / .float() / load into new storage), like the graph key of _launch_trunk."""
-        key = tuple(t.data_ptr() for s in self.steps for t in (s.bn.running_mean, s.bn.running_var))
+        key = self.trunk._ptr_epoch
         if b.get("table_key") == key:
             return
         rows = b["rows"]
@@ -309,7 +309,7 @@ class TrunkPlan:
         The key covers every pointer baked into the graph."""
         if not self.use_graph:
             return self._run_trunk(b, N, S, training)
-        key = (N, S, bool(training), self._wkey, tuple(t.data_ptr() for s in self.steps for t in (s.bn.weight, s.bn.bias, s.bn.running_mean, s.bn.running_var)))
+        key = (N, S, bool(training), self._wkey)       # _wkey carries the trunk's pointer epoch: every pointer baked into the graph
         g = self._graphs.get(key)
         if g is not None:
             g.replay()

@@ -48,6 +48,24 @@ class capture_guard:
         return False
 
 
+class on_stream:
+    """``with torch.cuda.stream(s)`` without its per-entry device query (torch's StreamContext asks the runtime for the device count
+    on every construction: ~20 us, a dozen times per step).  Single device per process (one process per GPU)."""
+    __slots__ = ("s", "prev")
+
+    def __init__(self, stream):
+        self.s = stream
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_stream(self.s.device)
+        torch.cuda.set_stream(self.s)
+        return self.s
+
+    def __exit__(self, *exc):
+        torch.cuda.set_stream(self.prev)
+        return False
+
+
 def parse_dtype(x) -> int:
     if isinstance(x, int):
         return x
@@ -797,7 +815,9 @@ class AttnDecoderEngine:
             setattr(s, k, ptr(st[k]))
         return s
 
-    def sample_fwd(self, params, features, fmap, Lc: int, temperature: float, pretrain: bool = False, noise_u=None, seed: int = 0):
+    def sample_fwd(self, params, features, fmap, Lc: int, temperature: float, pretrain: bool = False, noise_u=None, seed: int = 0,
+                   state=None, out=None, ids=None):
+        """``state`` / ``out`` / ``ids``: caller-owned buffers (alloc_state; the fused step driver pre-allocates them)."""
         self.check_params(params)
         require_gpu(features, fmap, noise_u)
         B = features.shape[0]
@@ -816,9 +836,9 @@ class AttnDecoderEngine:
             noise_u = noise_u.contiguous()
         dev = features.device
         self.prepare(params)
-        st = self.alloc_state(B, Lc, dev)
-        out = torch.empty(B, Lc, self.V, device=dev, dtype=self.act)
-        ids = torch.empty(B, Lc, device=dev, dtype=torch.int64)
+        st = dict(state) if state is not None else self.alloc_state(B, Lc, dev)
+        out = out if out is not None else torch.empty(B, Lc, self.V, device=dev, dtype=self.act)
+        ids = ids if ids is not None else torch.empty(B, Lc, device=dev, dtype=torch.int64)
         L.check(L.load().gic_attn_sample_fwd(
             C.byref(self.dims(B, Lc)), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
             ptr(features.contiguous()), ptr(fmap), ptr(noise_u), int(seed) & (2 ** 64 - 1), float(temperature), int(bool(pretrain)),
@@ -826,19 +846,9 @@ class AttnDecoderEngine:
         st["fmap"] = fmap
         return out, ids, st
 
-    def sample_bwd(self, params, st, out, ids, d_out, temperature: float, pretrain: bool = False):
-        """Returns [grads in NAMES order ..., d_features]."""
-        B, Lc = ids.shape
-        dev = out.device
+    def alloc_bwd_ws(self, B: int, Lc: int, dev):
         f32 = torch.float32
-        if d_out.dtype != self.act:
-            t = d_out.contiguous()
-            dst = torch.empty(t.shape, device=dev, dtype=self.act)
-            cast2d(t, dst, t.numel() // self.V, self.V, self.V, self.V)
-            d_out = dst
-        d_out = d_out.contiguous()
-        self.prepare(params)
-        ws = {
+        return {
             "dlogits": torch.empty(B, Lc, self.V, device=dev, dtype=self.act),
             "dhout": torch.empty(B, Lc, self.H, device=dev, dtype=f32),
             "dgates": torch.empty(Lc, B, 4 * self.H, device=dev, dtype=self.act),
@@ -852,10 +862,24 @@ class AttnDecoderEngine:
             "dwa_rows": torch.empty(B, self.A, device=dev, dtype=f32),
             "dx": torch.empty(Lc * B, self.E, device=dev, dtype=f32),
         }
+
+    def sample_bwd(self, params, st, out, ids, d_out, temperature: float, pretrain: bool = False, ws=None, grads=None):
+        """Returns [grads in NAMES order ..., d_features].  ``ws`` (alloc_bwd_ws) / ``grads`` (12 tensors): caller-owned buffers."""
+        B, Lc = ids.shape
+        dev = out.device
+        f32 = torch.float32
+        if d_out.dtype != self.act:
+            t = d_out.contiguous()
+            dst = torch.empty(t.shape, device=dev, dtype=self.act)
+            cast2d(t, dst, t.numel() // self.V, self.V, self.V, self.V)
+            d_out = dst
+        d_out = d_out.contiguous()
+        self.prepare(params)
+        ws = ws if ws is not None else self.alloc_bwd_ws(B, Lc, dev)
         w = L.AttnBwdWs()
         for k, v in ws.items():
             setattr(w, k, ptr(v))
-        grads = [torch.empty_like(p) for p in params] + [torch.empty(B, self.E, device=dev, dtype=f32)]
+        grads = grads if grads is not None else [torch.empty_like(p) for p in params] + [torch.empty(B, self.E, device=dev, dtype=f32)]
         L.check(L.load().gic_attn_sample_bwd(
             C.byref(self.dims(B, Lc)), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
             C.byref(w), ptr(st["fmap"]), ptr(out), ptr(ids), ptr(d_out), float(temperature), int(bool(pretrain)),

@@ -27,6 +27,7 @@ class FusedAdvStep:
         self.gen_arena, self.disc_arena = gen_arena, disc_arena
         self.reducer = reducer
         self.cgan = int(args.conditional_gan) == 1
+        self.attn = hasattr(gen.decoder, "attn")         # visual-attention decoder (cfg4): the roll-out also takes the trunk's feature map
         self.dec = gen.decoder.engine()
         self.den = disc.engine()
         self._buf: Dict[tuple, dict] = {}
@@ -34,7 +35,8 @@ class FusedAdvStep:
         self._disc_grads = None
         self.overlap = not os.environ.get("GIC_NO_STREAM_OVERLAP")
         self.trace = None
-        self.use_graph = not (os.environ.get("GIC_NO_STEP_GRAPH") or os.environ.get("GIC_NO_GRAPH"))
+        # (the attention kernels take temperature / seed by value: that step stays eager launches)
+        self.use_graph = not (os.environ.get("GIC_NO_STEP_GRAPH") or os.environ.get("GIC_NO_GRAPH")) and not self.attn
         self._graphs: Dict[tuple, dict] = {}
         self._warm: set = set()
 
@@ -125,9 +127,9 @@ class FusedAdvStep:
     def _take_and_prefetch(self, images, train, main, ev_start, next_images, next_train):
         """This step's trunk features (the look-ahead pass of the previous step, or a pass now), then the NEXT batch's pass on its stream."""
         enc = self.gen.encoder
-        trunk_feats = enc.take_trunk(images, train, main)
+        trunk_feats = enc.take_trunk_with_map(images, train, main) if self.attn else enc.take_trunk(images, train, main)
         if next_images is not None:          # the prefetched output is a private copy: the next trunk pass may start now
-            enc.prefetch_trunk(next_images, train if next_train is None else next_train, ev_start, mark=self._mark)
+            enc.prefetch_trunk(next_images, train if next_train is None else next_train, ev_start, mark=self._mark, want_map=self.attn)
         return trunk_feats
 
     def _body(self, buf, captions, trunk, images, T, train, noise_u, km, seeds, scal, opt_step, main, ev_start) -> dict:
@@ -147,13 +149,13 @@ class FusedAdvStep:
         lg = buf["logits"]
 
         # compute-dtype weight images are refreshed on the side streams, under the encoder
-        with torch.cuda.stream(s_gen):
+        with engine.on_stream(s_gen):
             s_gen.wait_event(ev_start)
             self.dec.prepare(gparams)
             ev_gprep = s_gen.record_event()
 
         # ---- D(real) (training.py:162), concurrently with the generator's forward
-        with torch.cuda.stream(s_real):
+        with engine.on_stream(s_real):
             s_real.wait_event(ev_start)
             self.den.prepare(dparams)
             ev_dprep = s_real.record_event()
@@ -167,8 +169,12 @@ class FusedAdvStep:
             self._mark("D(real) fwd done [s_real]", s_real)
 
         # ---- features (training.py:144-147) and one roll-out (training.py:150)
+        fmap = None
         if self.cgan:
             trunk_feats = trunk() if callable(trunk) else trunk
+            if self.attn:
+                trunk_feats, fmap = trunk_feats
+                fmap = fmap.view(fmap.shape[0], -1, fmap.shape[-1])
             feats = gen.encoder.forward_fused(images, train, trunk_feats=trunk_feats)
         else:
             feats = engine.embedding_fwd(gparams[0], buf["ones"])
@@ -176,8 +182,12 @@ class FusedAdvStep:
         main.wait_event(ev_gprep)
         # (measured: issuing the roll-out from a high-priority stream does not win it CU slots from the look-ahead trunk pass --
         # it finished only after the whole trunk pass -- so it stays on the main stream)
-        probs, ids, dst = self.dec.sample_fwd(gparams, feats, L, T, False, noise_u, seeds[3], state=buf["dec_state"],
-                                              out=buf["probs"], ids=buf["ids"], dev_scalars=scal, seed_slot=3)
+        if self.attn:
+            probs, ids, dst = self.dec.sample_fwd(gparams, feats, fmap, L, T, False, noise_u, seeds[3], state=buf["dec_state"],
+                                                  out=buf["probs"], ids=buf["ids"])
+        else:
+            probs, ids, dst = self.dec.sample_fwd(gparams, feats, L, T, False, noise_u, seeds[3], state=buf["dec_state"],
+                                                  out=buf["probs"], ids=buf["ids"], dev_scalars=scal, seed_slot=3)
         self._mark("roll-out done", main)
 
         # ---- D(fake), D(gen) (training.py:163-164): one pass up to the highway layer, two dropout draws + heads
@@ -194,7 +204,7 @@ class FusedAdvStep:
         self._mark("losses done", main)
 
         # ---- G path on its stream: g_loss -> D(gen) input grad -> decoder -> encoder head (training.py:169 minus the step)
-        with torch.cuda.stream(s_gen):
+        with engine.on_stream(s_gen):
             s_gen.wait_event(ev_loss)
             if overlap and scal is None:         # (a captured step keeps `lgrads` alive in the graph's own pool)
                 lgrads["dg_out"].record_stream(s_gen)
@@ -206,8 +216,10 @@ class FusedAdvStep:
                              ws=buf["disc_ws_gen"], d_inp=buf["d_probs"])
                 ev_dgen = s_gen.record_event()                     # D's weights are free to change from here on
                 self._mark("D(gen) input-grad done [s_gen]", s_gen)
-                early = self._early_bucket() if self.reducer is not None else None
-                if early is None:
+                early = self._early_bucket() if (self.reducer is not None and not self.attn) else None
+                if self.attn:
+                    self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"], grads=g_grads + [buf["d_feat"]])
+                elif early is None:
                     self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"],
                                         grads=g_grads + [buf["d_feat"]], dev_scalars=scal)
                 else:
@@ -240,8 +252,8 @@ class FusedAdvStep:
             # collectives run one after the other on the reducer's stream, in the order they become ready:
             # G's early bucket (above), D's arena (now), the rest of G's arena (when the G path is through)
             ev_dred = self.reducer.start(self.disc_arena.grad)
-            with torch.cuda.stream(s_gen):
-                early = self._early_bucket() if a.adv_loss_type != "rsgan" else None
+            with engine.on_stream(s_gen):
+                early = self._early_bucket() if (a.adv_loss_type != "rsgan" and not self.attn) else None
                 if early is None:
                     self.reducer.start(self.gen_arena.grad)
                 else:
@@ -388,7 +400,7 @@ class FusedAdvStep:
             buf["caps_in"].copy_(captions)
             scal.set(float(self.gen.decoder.temperature), [SEEDS.next() for _ in range(4)])
             ev_start = main.record_event()
-            with torch.cuda.stream(s_real):
+            with engine.on_stream(s_real):
                 s_real.wait_event(ev_start)
                 run("d_real", s_real)
                 ev_real = s_real.record_event()
@@ -398,7 +410,7 @@ class FusedAdvStep:
             main.wait_event(ev_real)
             run("d_fake", main)
             ev_loss = main.record_event()
-            with torch.cuda.stream(s_gen):
+            with engine.on_stream(s_gen):
                 s_gen.wait_event(ev_loss)
                 run("g_dgen", s_gen)
                 ev_dgen = s_gen.record_event()       # D's weights are free to change from here on

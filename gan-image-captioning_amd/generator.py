@@ -345,7 +345,7 @@ class Encoder(nn.Module):
         if getattr(self, "_s_pre", None) is None:
             self._s_pre = torch.cuda.Stream(device=images.device)
         s = self._s_pre
-        with torch.cuda.stream(s):
+        with engine.on_stream(s):
             s.wait_event(after)                 # `images` is ready
             busy, self._busy = getattr(self, "_busy", None), None
             if busy is not None:
@@ -378,6 +378,24 @@ class Encoder(nn.Module):
         feats = self.trunk_features(images, training).clone()
         self._busy = stream.record_event()
         return feats
+
+    def take_trunk_with_map(self, images, training: bool, stream):
+        """(trunk features, the trunk's last feature map [N, h, w, C]) of ``images`` on ``stream`` for the attention decoder: the
+        look-ahead pass's private copies if this very tensor was announced (prefetch_trunk(want_map=True)), else a pass now."""
+        pre, self._pre = getattr(self, "_pre", None), None
+        if pre is not None:
+            stream.wait_event(pre[3])           # also orders a synchronous pass behind an unused look-ahead (shared buffers)
+            if pre[0] is images and pre[1] == bool(training) and pre[4] is not None:
+                pre[2].record_stream(stream)
+                pre[4].record_stream(stream)
+                return pre[2], pre[4]
+        busy = getattr(self, "_busy", None)
+        if busy is not None:
+            stream.wait_event(busy)
+        feats = self.trunk_features(images, training).clone()
+        fmap = self.resnet._plan.last_map(images.shape[0], images.shape[2]).clone()
+        self._busy = stream.record_event()
+        return feats, fmap
 
     # ---- direct (no autograd) forms used by the fused step driver
     def trunk_features(self, images, training: bool):

@@ -87,7 +87,6 @@ class GANInstructor:
         if self.attention:
             if getattr(args, "adv_mode", "relgan") != "relgan":
                 raise ValueError("--decoder attention is trained with the relaxation (--adv-mode relgan)")
-            args.step_impl = "autograd"        # the attention decoder runs through the module API (autograd.Function wrappers)
         if self.dist.world_size > 1:
             parallel.broadcast_module(self.gen, self.dist)
             parallel.broadcast_module(self.disc, self.dist)

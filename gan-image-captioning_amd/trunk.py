@@ -82,6 +82,20 @@ class ResNetTrunk(nn.Module):
             self.add_module(k, v)
         self.out_features = cin
         self._plan = None
+        # bumped whenever tensors of this module may have MOVED (Module._apply: .to() / .float() / .cuda(); load_state_dict): the
+        # execution plan keys the pointers baked into its replayed hipGraph and its device tables on it instead of calling
+        # data_ptr() on ~320 tensors per forward (0.1 ms of host time per step).  Values changing in place need no such signal:
+        # BatchNorm affine / running tensors are read through their pointers, conv weights carry their own _version.
+        self._ptr_epoch = 0
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._bump_ptr_epoch())
+
+    def _bump_ptr_epoch(self) -> None:
+        self._ptr_epoch += 1
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._ptr_epoch += 1
+        return out
 
     def stages(self) -> List[nn.Sequential]:
         return [getattr(self, str(i)) for i in (4, 5, 6, 7)]

@@ -83,11 +83,13 @@ def attn_decoder_sample(gp: O.Params, features: Tensor, fmap: Tensor, max_captio
 
 def attn_adv_step(gp: O.Params, dp: O.Params, captions: Tensor, us: Sequence[Tensor], masks: Optional[Sequence[Tensor]], temperature: float,
                   trunk_feat: Tensor, fmap: Tensor, loss_type: str = "standard", num_rep: int = 64,
-                  force_ids: Optional[Tensor] = None) -> dict:
+                  force_ids: Optional[Tensor] = None, clip_norm: float = 5.0, gen_opt: Optional[O.AdamState] = None,
+                  disc_opt: Optional[O.AdamState] = None) -> dict:
     """The adversarial G+D step of oracle/cpu_step.adv_step (body of reference src/training.py:144-169 in the fixed order) with the
     attention decoder as the sampler: features = encoder head(trunk_feat) -> attn_decoder_sample over ``fmap`` [B,P,C] -> the three
     discriminator passes -> losses -> raw gradients of D (from d_loss) and of G's trainable tensors (decoder incl. attention, encoder
-    head; from g_loss).  No optimizer (the composed test compares gradients).  ``force_ids``: as in cpu_step.decoder_sample."""
+    head; from g_loss), then clip + Adam when optimizers are given (gp / dp updated in place, as cpu_step.adv_step).  ``force_ids``: as
+    in cpu_step.decoder_sample."""
     vocab = gp["decoder.linear.weight"].shape[0]
     g_names = [k for k in gp if k.startswith(("decoder.", "encoder.linear.", "encoder.bn."))]
     g_leaf = {k: gp[k].detach().clone().requires_grad_(True) for k in g_names}
@@ -102,5 +104,10 @@ def attn_adv_step(gp: O.Params, dp: O.Params, captions: Tensor, us: Sequence[Ten
     g_loss, d_loss = O.get_losses(d_real, d_fake, g_out, loss_type)
     d_grads = dict(zip(d_leaf, torch.autograd.grad(d_loss, list(d_leaf.values()), retain_graph=True)))
     g_t = torch.autograd.grad(g_loss, list(g_leaf.values()), allow_unused=True)
+    g_grads = {k: g for k, g in zip(g_leaf, g_t) if g is not None}
+    if disc_opt is not None:
+        disc_opt.step(dp, O.clip_grad_norm(d_grads, clip_norm)[0])
+    if gen_opt is not None:
+        gen_opt.step(gp, O.clip_grad_norm(g_grads, clip_norm)[0])
     return {"probs": gen.detach(), "ids": ids, "g_loss": float(g_loss.detach()), "d_loss": float(d_loss.detach()),
-            "d_grads_raw": d_grads, "g_grads_raw": {k: g for k, g in zip(g_leaf, g_t) if g is not None}}
+            "d_grads_raw": d_grads, "g_grads_raw": g_grads}

@@ -57,7 +57,10 @@ def seqgan_step(gp: O.Params, dp: O.Params, captions: Tensor, u_sample: Sequence
             flen = torch.arange(1, seqlen).repeat_interleave(N * bsz)
             _, mc_ids = O.decoder_sample(gp if trunk_feat is None else g_leaf, f_big, seqlen, 1.0,
                                          [u_mc[t] for t in range(seqlen)], force_ids=force, force_len=flen)
-            mc_logit = O.disc_forward(dp, torch.nn.functional.one_hot(mc_ids, vocab).float(), None, num_rep)
+            # D's reward evaluation in chunks of rows (the dense one-hot of all (L-1)*N*B roll-outs at BASELINE sizes is tens of GB;
+            # captions are independent in D's eval-mode forward, so the result is the same)
+            mc_logit = torch.cat([O.disc_forward(dp, torch.nn.functional.one_hot(mc_ids[r0:r0 + 608], vocab).float(), None, num_rep)
+                                  for r0 in range(0, mc_ids.shape[0], 608)])
             score = torch.sigmoid(mc_logit).view(seqlen - 1, N, bsz, num_rep).mean(dim=(1, 3))          # [L-1, B]
             rewards[:, :seqlen - 1] = score.t()
         full = O.disc_forward(dp, torch.nn.functional.one_hot(Y, vocab).float(), None, num_rep)

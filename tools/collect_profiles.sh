@@ -3,7 +3,7 @@
 # Every rocprofv3 command puts the program itself after `--` and collects counters in passes of their own (no trace domains beside --pmc
 # other than --kernel-trace).
 set -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 O=$PWD/gpurun_out/$R
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
