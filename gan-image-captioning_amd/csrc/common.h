@@ -153,6 +153,15 @@ struct Philox {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// 64-bit key whose unsigned order is (value ascending, index DESCENDING): atomicMax over the keys of a row = its first maximal index
+// (the argmax of a caption's Gumbel-perturbed logits across the vocabulary tiles of several workgroups; zero = below every key)
+__device__ __forceinline__ unsigned long long row_key(float v, int idx) {
+  const unsigned int b = __float_as_uint(v);
+  const unsigned int ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  return ((unsigned long long)ord << 32) | (unsigned long long)(~(unsigned int)idx);
+}
+__device__ __forceinline__ int row_key_index(unsigned long long k) { return (int)(~(unsigned int)(k & 0xffffffffull)); }
+
 // Dynamic LDS beyond 64 KB must be granted per kernel AND per device (hipFuncAttributeMaxDynamicSharedMemorySize).  LdsGrant = what the
 // kernel already has on each device: one static per kernel instantiation at the call site, so the attribute is set once per device
 // (outside any stream capture: every plan runs its first pass eagerly).  The slow path is serialised, so two host threads that need

@@ -346,6 +346,23 @@ __global__ void rollout_join_kernel(const unsigned char* __restrict__ src_xh, un
   }
 }
 
+// ids-only generic roll-out step behind gemm_gumbelmax: token = index of the row's key (or the forced one), ids[b, t], and the token's
+// embedding row into the next step's x slot; one 256-thread block per 4 rows
+template <typename TA>
+__global__ __launch_bounds__(256) void rollout_pick_kernel(const unsigned long long* __restrict__ rowkey, int64_t* __restrict__ ids, long ids_stride,
+                                                           const float* __restrict__ embed, TA* __restrict__ x_next, long ld_x, int rows, int V,
+                                                           int E, const int64_t* __restrict__ force_ids, const int32_t* __restrict__ force_len,
+                                                           int t) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= rows) return;
+  int id = row_key_index(rowkey[b]);
+  if (force_ids && (!force_len || t < force_len[b])) id = (int)force_ids[(long)b * ids_stride];
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  if (lane == 0) ids[(long)b * ids_stride] = id;
+  if (x_next)
+    for (int e = lane; e < E; e += 64) x_next[(long)b * ld_x + e] = from_f32<TA>(embed[(long)id * E + e]);
+}
+
 struct Ctx {
   int B, L, V, E, H, NL, dt;
   int din(int l) const { return l == 0 ? E : H; }
@@ -455,6 +472,12 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
   // resumed roll-outs: at step t only the first act[t] rows exist; the rows that join take their state from the earlier call
   const int32_t* act = (opt && opt->resume_from) ? opt->host_active_rows : nullptr;
   if (act) GIC_PROPAGATE(hipMemcpyAsync(ids, f_ids, (size_t)B * L * sizeof(int64_t), hipMemcpyDeviceToDevice, stream) == hipSuccess ? GIC_OK : GIC_ERR_LAUNCH);
+  // ids-only roll-outs in the bf16 mode: one 64-bit argmax key per (step, row) in the logits scratch (gemm_gumbelmax); zeroed once
+  unsigned long long* rowkeys = nullptr;
+  if (!out && !pretrain && c.dt == DT_BF16 && V % 4 == 0 && (long)L * 8 <= (long)V * 4 && ((uintptr_t)st->logits & 7) == 0) {
+    rowkeys = (unsigned long long*)st->logits;                  // [L][B] keys inside the [B, V] f32 scratch (L * 8 <= V * 4 bytes per row)
+    GIC_PROPAGATE(fill_zero(rowkeys, (size_t)L * B * sizeof(unsigned long long), stream));
+  }
 
   for (int t = 0; t < L; ++t) {
     const int M = act ? act[t] : B;                     // rows that take part in this step
@@ -495,6 +518,28 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
                          xh_n + c.din(l), ld, h_up, h_up ? c.ldx(l + 1) : 0, h_out, (long)L * H, M, H);
       GIC_CHECK_LAUNCH("lstm_pointwise_fwd");
     }
+    TA* x_next = (TA*)st->xh[0] + (long)(t + 1) * B * c.ldx(0);
+    const float* u_t = noise_u ? noise_u + (long)t * B * V : nullptr;
+    if (!out && !pretrain && rowkeys) {
+      // ids only (Monte-Carlo roll-outs): vocabulary product with the Gumbel-max in its epilogue -- the [rows, V] logits never reach
+      // memory (389 MB written and read again per step at 9728 rows), then key -> token -> next input row
+      const int l = NL - 1;
+      const long ld = c.ldx(l);
+      GemmDesc g;
+      g.A = S->wout; g.lda = H; g.B = (TA*)st->xh[l] + (long)(t + 1) * B * ld + c.din(l); g.ldb = ld;
+      g.M = V; g.N = M; g.K = H; g.in_dtype = c.dt; g.out_dtype = DT_F32;
+      g.gm_rowkey = rowkeys + (long)t * B; g.gm_bias = P->b_out; g.gm_u = u_t; g.gm_ldu = V; g.gm_temperature = temperature;
+      g.seed = seed; g.stream = (uint64_t)t;
+      const int s = gemm_gumbelmax(g, stream);
+      if (s == GIC_OK) {
+        hipLaunchKernelGGL((rollout_pick_kernel<TA>), dim3((unsigned)cdiv(M, 4)), dim3(256), 0, stream, (const unsigned long long*)g.gm_rowkey,
+                           ids + t, (long)L, P->embed, x_next, c.ldx(0), M, V, E, f_ids ? f_ids + t : nullptr, f_len, t);
+        GIC_CHECK_LAUNCH("rollout_pick");
+        continue;
+      }
+      if (s != GIC_ERR_UNSUPPORTED) return s;
+      rowkeys = nullptr;                        // shapes the fused product declines: the separate launches from here on
+    }
     {  // vocabulary projection on the last layer's h_t (lives in XH_last[t+1][:, Din:])
       const int l = NL - 1;
       const long ld = c.ldx(l);
@@ -504,8 +549,6 @@ int sample_fwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
       g.M = M; g.N = V; g.K = H; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.bias = P->b_out;
       GIC_PROPAGATE(gemm(g, stream));
     }
-    TA* x_next = (TA*)st->xh[0] + (long)(t + 1) * B * c.ldx(0);
-    const float* u_t = noise_u ? noise_u + (long)t * B * V : nullptr;
     TA* out_t = out ? (TA*)out + (long)t * V : nullptr;
     constexpr bool kFast = sizeof(TA) == 2;
     if (V % 4 == 0 && V <= 4096) {

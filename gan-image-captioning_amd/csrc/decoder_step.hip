@@ -96,13 +96,7 @@ template <> __device__ __forceinline__ void mma<float>(f32x4& acc, const Frag<fl
   for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[s], b.v[s], acc, 0, 0, 0);
 }
 
-// 64-bit key whose unsigned order is (value ascending, index DESCENDING): atomicMax over the keys of a row = its first maximal index
-__device__ __forceinline__ unsigned long long row_key(float v, int idx) {
-  const unsigned int b = __float_as_uint(v);
-  const unsigned int ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-  return ((unsigned long long)ord << 32) | (unsigned long long)(~(unsigned int)idx);
-}
-__device__ __forceinline__ int row_key_index(unsigned long long k) { return (int)(~(unsigned int)(k & 0xffffffffull)); }
+// (row_key / row_key_index: common.h)
 
 // (value, index) argmax across the 64 lanes: larger value wins, equal values -> smaller index (first maximal index)
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {

@@ -13,7 +13,7 @@
 
 namespace gic {
 
-enum GemmEpi { EPI_PLAIN = 0, EPI_HIGHWAY = 1, EPI_BNSTATS = 2 };
+enum GemmEpi { EPI_PLAIN = 0, EPI_HIGHWAY = 1, EPI_BNSTATS = 2, EPI_GUMBELMAX = 3 };
 
 struct GemmDesc {
   const void* A = nullptr;
@@ -61,11 +61,25 @@ struct GemmDesc {
   const float* res_gamma = nullptr; const float* res_beta = nullptr;
   float res_inv_count = 0.f;
   void* out_wb = nullptr;
+  // ---- EPI_GUMBELMAX (gemm_gumbelmax below): C is NOT written.  Rows m = vocabulary entries (A = W_out [V, H]), columns n = roll-out
+  //      rows (B = their hidden states): key[n] = atomicMax over m of row_key((acc + gm_bias[m] + gumbel(u[n, m])) * gm_temperature, m)
+  //      -- the token of an ids-only roll-out step (generator.py:68-73 with the softmax skipped: it is monotone) without the [rows, V]
+  //      logits ever reaching memory.  u: gm_u (explicit uniforms, row n at gm_u + n * gm_ldu) or Philox(seed | seed_dev, stream) indexed
+  //      as the unfused kernels index it (4 consecutive vocabulary entries of a row per call).
+  unsigned long long* gm_rowkey = nullptr;
+  const float* gm_bias = nullptr;
+  const float* gm_u = nullptr; long gm_ldu = 0;
+  float gm_temperature = 1.f;
   int n_fast = 0;           // tile8: the output-channel tiles of a row tile are neighbours on one XCD (xcd_share_a) instead of the row tiles of a channel tile
   int dbg = 0;              // phase-ablation knob, honoured only by -DGIC_STAMPS tool builds
 };
 
 // Enqueue on `stream`. Returns GIC_OK or a negative Status (message via gic_last_error()).
 int gemm(const GemmDesc& d, hipStream_t stream);
+
+// The vocabulary product of an ids-only roll-out step fused with Gumbel-max (EPI_GUMBELMAX above): bf16 k-contiguous operands, M = V a
+// multiple of 4, many roll-out rows (the 8-wave kernel's grid conditions).  GIC_ERR_UNSUPPORTED (no message) when the shapes do not
+// qualify: the caller runs the product and the Gumbel-argmax kernel separately.
+int gemm_gumbelmax(const GemmDesc& d, hipStream_t stream);
 
 }  // namespace gic

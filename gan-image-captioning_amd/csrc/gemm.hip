@@ -540,7 +540,7 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
   constexpr int NL = CA + CB + (ARES ? CA : 0);              // LDS-DMA instructions per thread per stage
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, R_BYTES = ARES ? A_BYTES : 0, STAGE = A_BYTES + B_BYTES + R_BYTES;
   constexpr int OSZ = sizeof(TO), OVE = 16 / OSZ, SC = BN * OSZ + 16;
-  constexpr int EPI_BYTES = EPI == EPI_HIGHWAY ? BM * (BN + 4) * 4 : BM * SC + 8 * (BN / 2) * 2 * 4;   // highway stages h in f32
+  constexpr int EPI_BYTES = EPI == EPI_HIGHWAY ? BM * (BN + 4) * 4 : (EPI == EPI_GUMBELMAX ? 8 * BN * 4 : BM * SC + 8 * (BN / 2) * 2 * 4);   // highway stages h in f32
   constexpr int RING_BYTES = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
   constexpr int ABN_MAXK = AMAXK;                             // A-side BatchNorm: [scale, shift] per input channel behind the ring
   constexpr int SMEM_BYTES = RING_BYTES + (ABN ? ABN_MAXK * 8 : 0) + (ARES ? ABN_MAXK * 8 : 0);     // ARES: + the shortcut's [scale, shift]
@@ -828,6 +828,66 @@ __global__ __launch_bounds__(512) void tile8_kernel(const GemmDesc d, const unsi
   __syncthreads();
   STAMP(3);
 
+  if constexpr (EPI == EPI_GUMBELMAX) {
+    // rows m = vocabulary entries, columns n = roll-out rows.  A lane's four accumulator registers of a 16x16 block are four CONSECUTIVE
+    // vocabulary entries of one roll-out row: one Philox4x32 call (or one 16-byte load of explicit uniforms) and one bias load per block.
+    float* sV = (float*)smem;                    // [4 (wr)][BN] best value
+    int* sI = (int*)(smem + 4 * BN * 4);         // [4 (wr)][BN] its vocabulary index
+    const float eps = 1e-10f;                    // generator.py:84
+    const uint64_t seed = d.seed_dev ? *d.seed_dev : d.seed;
+    const float T = d.gm_temperature;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nl = wc * (BN / 2) + j * 16 + lr;
+      const int n = bn0 + nl;
+      float best = -INFINITY;
+      int best_i = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m0 = bm0 + wr * 32 + i * 16 + lg * 4;
+        if (m0 < M && n < N) {                   // (M % 4 == 0: a quad is inside the vocabulary or past it as a whole)
+          const float4 bv = *(const float4*)(d.gm_bias + m0);
+          const float bia[4] = {bv.x, bv.y, bv.z, bv.w};
+          float uu[4];
+          if (d.gm_u) {
+            const float4 uv = *(const float4*)(d.gm_u + (long)n * d.gm_ldu + m0);
+            uu[0] = uv.x; uu[1] = uv.y; uu[2] = uv.z; uu[3] = uv.w;
+          } else {
+            uint32_t r0, r1, r2, r3;
+            Philox::gen4(seed, d.stream, (uint64_t)n * (uint64_t)(M >> 2) + (uint64_t)(m0 >> 2), r0, r1, r2, r3);
+            uu[0] = Philox::u01(r0); uu[1] = Philox::u01(r1); uu[2] = Philox::u01(r2); uu[3] = Philox::u01(r3);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float g = -__logf(-__logf(uu[r] + eps) + eps);      // (bf16 compute mode: the hardware log, as the unfused kernel)
+            const float y = (acc[i][j][r] + bia[r] + g) * T;
+            if (y > best) { best = y; best_i = m0 + r; }
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {       // the four lane groups hold other vocabulary rows of the same roll-out row
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(best_i, o, 64);
+        if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+      }
+      if (lg == 0) { sV[wr * BN + nl] = best; sI[wr * BN + nl] = best_i; }
+    }
+    __syncthreads();
+    if (tid < BN && bn0 + tid < N) {
+      float best = sV[tid];
+      int best_i = sI[tid];
+#pragma unroll
+      for (int r = 1; r < 4; ++r) {
+        const float ob = sV[r * BN + tid];
+        const int oi = sI[r * BN + tid];
+        if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+      }
+      if (best_i != 0x7fffffff) atomicMax(d.gm_rowkey + bn0 + tid, row_key(best, best_i));
+    }
+    STAMP(5);
+    return;
+  }
   TO* __restrict__ C = (TO*)d.C;
   if constexpr (EPI == EPI_HIGHWAY) {
     // h = acc + bias (saved); y = sig(h) relu(h) + (1 - sig(h)) x; C = y * keep * keep_scale.
@@ -1222,6 +1282,25 @@ int pick_epi(const GemmDesc& d, bool vec, hipStream_t stream) {
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
+
+int gemm_gumbelmax(const GemmDesc& d0, hipStream_t stream) {
+  GemmDesc d = d0;
+  static const bool off = getenv("GIC_NO_TILE8") != nullptr || getenv("GIC_NO_FUSED_GUMBELMAX") != nullptr;
+  GIC_CHECK_ARG(d.A && d.B && d.gm_rowkey && d.gm_bias, "gemm_gumbelmax: null operand");
+  if (off || d.in_dtype != DT_BF16 || !d.a_kc || !d.b_kc || d.M < 128 || d.M % 4 || d.K % 8 || d.lda % 8 || d.ldb % 8 || !aligned16(d.A) ||
+      !aligned16(d.B) || !aligned16(d.gm_bias) || (d.gm_u && (!aligned16(d.gm_u) || d.gm_ldu % 4)) || !(d.gm_temperature > 0.f))
+    return GIC_ERR_UNSUPPORTED;
+  const long a_elems = (long)(d.M - 1) * d.lda + d.K, b_elems = (long)(d.N - 1) * d.ldb + d.K;
+  const long tiles = (long)cdiv(d.M, 128) * cdiv(d.N, 128);
+  if (a_elems * 2 >= (1l << 31) || b_elems * 2 >= (1l << 31) || d.N < 128 || tiles < 160) return GIC_ERR_UNSUPPORTED;
+  d.epi = EPI_GUMBELMAX;
+  d.n_fast = xcd_share_a(2l * d.M * d.K, 2l * d.N * d.K, cdiv(d.N, 128));
+  const unsigned ab = (unsigned)(a_elems * 2), bb = (unsigned)(b_elems * 2);
+  if (tiles > 256) hipLaunchKernelGGL((tile8_kernel<float, 128, EPI_GUMBELMAX, false, 2>), dim3((unsigned)tiles), dim3(512), 0, stream, d, ab, bb);
+  else hipLaunchKernelGGL((tile8_kernel<float, 128, EPI_GUMBELMAX, false, 4>), dim3((unsigned)tiles), dim3(512), 0, stream, d, ab, bb);
+  GIC_CHECK_LAUNCH("gemm gumbelmax");
+  return GIC_OK;
+}
 
 int gemm(const GemmDesc& d0, hipStream_t stream) {
   GemmDesc d = d0;

@@ -728,3 +728,32 @@ def test_api_corners_match_reference_golden(E, dev):
             close_mostly(gt, wantd[n], 2e-3, 1e-4, n, 1e-2, 1.5e-2)
         else:
             close(gt, wantd[n], rtol=2e-3, atol_scale=1e-4, what=n, atol_abs=1e-6)
+
+
+@pytest.mark.parametrize("explicit_noise", [False, True])
+def test_ids_only_rollout_with_the_gumbel_max_in_the_vocabulary_product(E, dev, explicit_noise):
+    """An ids-only roll-out of many rows in the bf16 mode (the Monte-Carlo roll-outs of the SeqGAN-style step) runs its vocabulary
+    product with the Gumbel-max in the epilogue (gemm.hip EPI_GUMBELMAX: swapped operands, one argmax key per row, no [rows, V] logits
+    in memory).  Same weights, inputs and noise (device Philox stream or explicit uniforms) through the probability-returning path
+    (separate product + Gumbel-softmax kernel) must give the same tokens (generator.py:68-73: argmax of softmax((o + g) T) = argmax
+    of o + g), up to bf16-level near-ties between the two products' summation orders."""
+    from gan_image_captioning_amd import _lib
+    B, L, V, Em, H = 640, 4, 10000, 64, 128                       # 79 x 5 = 395 tiles: the fused product engages
+    g = torch.Generator().manual_seed(31)
+    gp = {k: v * 4 for k, v in O.make_gen_params(V, Em, H, 1, g).items()}
+    eng = E.DecoderEngine(V, Em, H, 1, _lib.BF16)
+    assert eng.fused_rollout_rows() == 512 and B > 512             # beyond the fused step kernels: the generic-product path
+    params = dec_params(gp, dev)
+    feats = (torch.randn(B, Em, generator=g) * 0.5).to(dev)
+    u = torch.empty(L, B, V).uniform_(0, 1, generator=g).to(dev) if explicit_noise else None
+    _, ids_a, _ = eng.sample_fwd(params, feats, L, 1.0, noise_u=u, seed=99, ids_only=True)
+    probs, ids_b, _ = eng.sample_fwd(params, feats, L, 1.0, noise_u=u, seed=99)
+    torch.cuda.synchronize()
+    assert int(ids_a.min()) >= 0 and int(ids_a.max()) < V
+    agree0 = float((ids_a[:, 0] == ids_b[:, 0]).float().mean())     # step 0: identical inputs to both paths
+    agree = float((ids_a == ids_b).float().mean())                   # later steps inherit a flipped token's different input
+    assert agree0 >= 0.995 and agree >= 0.98, (agree0, agree)
+    assert len(torch.unique(ids_a)) > B                               # the noise differs from row to row and from step to step
+    # the token the ids-only path picked is (one of) the most probable under the other path's probabilities
+    p_pick = probs.float().gather(2, ids_a.unsqueeze(-1)).squeeze(-1)[:, 0]
+    assert float((p_pick >= probs.float()[:, 0].max(-1)[0] * 0.98).float().mean()) >= 0.995
