@@ -144,10 +144,14 @@ def roofline_probe(inst, args, cgan, step=None):
     if cgan:
         from gan_image_captioning_amd import encoder_engine
         traffic = None
+        name = None
         try:     # HBM bytes per launch: NOT measured by this run -- read from the committed rocprofv3 --pmc passes of this command
-            name = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))[-1]      # the latest round's
-            with open(os.path.join(ROOT, "profiles", name)) as fh:
-                traffic = json.load(fh)["conv_bnstats"]["hbm_bytes_per_launch"]
+            # (the committed passes are of the default workload: cfg2, batch 64, ResNet-50; other workloads report no traffic figure)
+            if args.adv_train_batch_size == CFG2["B"] and args.encoder_arch == "resnet50" and getattr(args, "decoder", "lstm") == "lstm" \
+                    and getattr(args, "adv_mode", "relgan") == "relgan":
+                name = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))[-1]      # the latest round's
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    traffic = json.load(fh)["conv_bnstats"]["hbm_bytes_per_launch"]
         except Exception:
             name = None
         in_step = conv_times_in_step(inst, step) if step is not None else None

@@ -235,12 +235,14 @@ int check_attn_dims(const gic_attn_dims* d, ACtx& c) {
 template <typename TA>
 int attn_fwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S, const gic_attn_state* st, const float* features,
                const void* fmap, const float* noise_u, uint64_t seed, float temperature, int pretrain, void* out, int64_t* ids,
-               hipStream_t stream) {
+               const float* h0, const float* c0, hipStream_t stream) {
   const int B = c.B, L = c.L, V = c.V, E = c.E, H = c.H;
   const long ld = c.ldx();
-  // slot 0: zero state, features -> x_0
+  // slot 0: initial (h, c) -- zeros, or the caller's states (sample(features, fmap, states=(h0, c0))) -- and features -> x_0
   GIC_PROPAGATE(fill_zero(st->xh, (size_t)B * ld * c.asz(), stream));
-  GIC_PROPAGATE(fill_zero(st->c, (size_t)B * H * sizeof(float), stream));
+  if (h0) GIC_PROPAGATE(cast2d(h0, DT_F32, H, (char*)st->xh + (size_t)(ld - H) * c.asz(), c.dt, ld, B, H, stream));
+  if (c0) GIC_PROPAGATE(cast2d(c0, DT_F32, H, st->c, DT_F32, H, B, H, stream));
+  else GIC_PROPAGATE(fill_zero(st->c, (size_t)B * H * sizeof(float), stream));
   GIC_PROPAGATE(cast2d(features, DT_F32, E, st->xh, c.dt, ld, B, E, stream));
   {  // fp = fmap W_f^T + b_f
     GemmDesc g;
@@ -406,15 +408,15 @@ int gic_attn_prepare(const gic_attn_dims* dims, const gic_attn_params* P, const 
 
 int gic_attn_sample_fwd(const gic_attn_dims* dims, const gic_attn_params* P, const gic_attn_shadow* S, const gic_attn_state* st,
                         const float* features, const void* fmap, const float* noise_u, uint64_t seed, float temperature, int pretrain,
-                        void* out, int64_t* ids, void* stream) {
+                        void* out, int64_t* ids, const float* h0, const float* c0, void* stream) {
   ACtx c;
   GIC_PROPAGATE(check_attn_dims(dims, c));
   GIC_CHECK_ARG(P && S && st && features && fmap && out && ids, "attn_sample_fwd: null argument");
   GIC_CHECK_ARG(P->embed && P->b_out && P->b_f && P->w_a && S->wcat && S->bsum && S->wout && S->wf && S->wh, "attn_sample_fwd: null weights");
   GIC_CHECK_ARG(st->xh && st->gates && st->c && st->hout && st->part && st->fproj && st->alpha && st->hproj, "attn_sample_fwd: null state buffer");
   if (c.dt == DT_F32)
-    return attn_fwd_t<float>(c, P, S, st, features, fmap, noise_u, seed, temperature, pretrain, out, ids, (hipStream_t)stream);
-  return attn_fwd_t<bf16_t>(c, P, S, st, features, fmap, noise_u, seed, temperature, pretrain, out, ids, (hipStream_t)stream);
+    return attn_fwd_t<float>(c, P, S, st, features, fmap, noise_u, seed, temperature, pretrain, out, ids, h0, c0, (hipStream_t)stream);
+  return attn_fwd_t<bf16_t>(c, P, S, st, features, fmap, noise_u, seed, temperature, pretrain, out, ids, h0, c0, (hipStream_t)stream);
 }
 
 int gic_attn_sample_bwd(const gic_attn_dims* dims, const gic_attn_params* P, const gic_attn_shadow* S, const gic_attn_state* st,

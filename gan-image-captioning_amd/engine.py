@@ -816,8 +816,9 @@ class AttnDecoderEngine:
         return s
 
     def sample_fwd(self, params, features, fmap, Lc: int, temperature: float, pretrain: bool = False, noise_u=None, seed: int = 0,
-                   state=None, out=None, ids=None):
-        """``state`` / ``out`` / ``ids``: caller-owned buffers (alloc_state; the fused step driver pre-allocates them)."""
+                   state=None, out=None, ids=None, states=None):
+        """``state`` / ``out`` / ``ids``: caller-owned buffers (alloc_state; the fused step driver pre-allocates them).
+        ``states`` = (h0, c0), each [1, B, H] or [B, H]: initial LSTM state (constants of the backward pass)."""
         self.check_params(params)
         require_gpu(features, fmap, noise_u)
         B = features.shape[0]
@@ -839,10 +840,16 @@ class AttnDecoderEngine:
         st = dict(state) if state is not None else self.alloc_state(B, Lc, dev)
         out = out if out is not None else torch.empty(B, Lc, self.V, device=dev, dtype=self.act)
         ids = ids if ids is not None else torch.empty(B, Lc, device=dev, dtype=torch.int64)
+        h0 = c0 = None
+        if states is not None:
+            h0, c0 = (t.detach().to(torch.float32).reshape(-1, self.H).contiguous() for t in states)
+            if tuple(h0.shape) != (B, self.H) or tuple(c0.shape) != (B, self.H):
+                raise ValueError(f"states must be (h0, c0), each [1, B={B}, H={self.H}]")
+            require_gpu(h0, c0)
         L.check(L.load().gic_attn_sample_fwd(
             C.byref(self.dims(B, Lc)), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
             ptr(features.contiguous()), ptr(fmap), ptr(noise_u), int(seed) & (2 ** 64 - 1), float(temperature), int(bool(pretrain)),
-            ptr(out), ptr(ids), stream_ptr()), "gic_attn_sample_fwd")
+            ptr(out), ptr(ids), ptr(h0), ptr(c0), stream_ptr()), "gic_attn_sample_fwd")
         st["fmap"] = fmap
         return out, ids, st
 

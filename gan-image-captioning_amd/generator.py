@@ -185,9 +185,10 @@ class Decoder(nn.Module):
 # ------------------------------------------------------------------------------------------ visual-attention decoder
 class _AttnSampleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, temperature, pretrain, max_len, noise_u, seed, fmap, features, *params):
+    def forward(ctx, eng, temperature, pretrain, max_len, noise_u, seed, states, fmap, features, *params):
         dparams = [p.detach() for p in params]
-        out, ids, st = eng.sample_fwd(dparams, features.detach().float(), fmap.detach(), max_len, temperature, pretrain, noise_u, seed)
+        out, ids, st = eng.sample_fwd(dparams, features.detach().float(), fmap.detach(), max_len, temperature, pretrain, noise_u, seed,
+                                      states=states)
         ctx.eng, ctx.temperature, ctx.pretrain, ctx.st, ctx.dparams = eng, temperature, pretrain, st, dparams
         ctx.save_for_backward(out, ids)
         ctx.mark_non_differentiable(ids)
@@ -198,7 +199,7 @@ class _AttnSampleFn(torch.autograd.Function):
         out, ids = ctx.saved_tensors
         grads = ctx.eng.sample_bwd(ctx.dparams, ctx.st, out, ids, d_out, ctx.temperature, ctx.pretrain)
         ctx.st = None
-        return (None, None, None, None, None, None, None, grads[-1], *grads[:-1])
+        return (None, None, None, None, None, None, None, None, grads[-1], *grads[:-1])
 
 
 class _AttnParams(nn.Module):
@@ -251,10 +252,10 @@ class AttnDecoder(nn.Module):
         """(outputs [B,L,V], ids [B,L]) as Decoder.sample; ``fmap`` [B, P, C]: the trunk's last feature map (no gradient into it)."""
         if fmap is None:
             raise ValueError("the attention decoder needs the trunk's feature map: sample(features, fmap)")
-        if states is not None:
-            raise NotImplementedError("the attention decoder starts from zero states")
+        if states is not None:          # (h0, c0), each [1, B, H] as nn.LSTM takes them (generator.py:55,61); constants of the backward pass
+            states = tuple(t.detach() for t in states)
         seed = 0 if noise_u is not None else SEEDS.next()
-        return _AttnSampleFn.apply(self.engine(), float(self.temperature), bool(pretrain), int(max_caption_len), noise_u, seed, fmap,
+        return _AttnSampleFn.apply(self.engine(), float(self.temperature), bool(pretrain), int(max_caption_len), noise_u, seed, states, fmap,
                                    features, *self.param_list())
 
 

@@ -50,13 +50,14 @@ def attention(gp: O.Params, fmap: Tensor, fproj: Tensor, h_prev: Tensor, prefix:
 
 def attn_decoder_sample(gp: O.Params, features: Tensor, fmap: Tensor, max_caption_len: int, temperature: float,
                         us: Optional[Sequence[Tensor]] = None, pretrain: bool = False, prefix: str = "decoder.",
-                        force_ids: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
-    """Returns (outputs [B,L,V], ids [B,L], alphas [B,L,P]); see the module docstring."""
+                        force_ids: Optional[Tensor] = None, states: Optional[Tuple[Tensor, Tensor]] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """Returns (outputs [B,L,V], ids [B,L], alphas [B,L,P]); see the module docstring.  ``states`` = (h0, c0), each [1, B, H]
+    (the `states` argument of the reference's Decoder.sample, src/generator.py:55,61); None = zeros."""
     bsz = features.shape[0]
     hid = gp[f"{prefix}lstm.weight_hh_l0"].shape[1]
     fproj = fmap @ gp[f"{prefix}attn.w_f"].t() + gp[f"{prefix}attn.b_f"]        # [B,P,A]
-    h = features.new_zeros(bsz, hid)
-    c = features.new_zeros(bsz, hid)
+    h = features.new_zeros(bsz, hid) if states is None else states[0].reshape(bsz, hid)
+    c = features.new_zeros(bsz, hid) if states is None else states[1].reshape(bsz, hid)
     x = features
     outs: List[Tensor] = []
     ids: List[Tensor] = []
