@@ -148,9 +148,9 @@ _SIGNATURES = {
     "gic_decoder_fused_rollout_rows": (C.c_int, [_P(DecoderDims), c_void_p]),
     "gic_attn_prepare": (C.c_int, [_P(AttnDims), _P(AttnParams), _P(AttnShadow), c_void_p]),
     "gic_attn_sample_fwd": (C.c_int, [_P(AttnDims), _P(AttnParams), _P(AttnShadow), _P(AttnState), c_void_p, c_void_p, c_void_p, C.c_uint64,
-                                      C.c_float, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                      C.c_float, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, c_void_p]),
     "gic_attn_sample_bwd": (C.c_int, [_P(AttnDims), _P(AttnParams), _P(AttnShadow), _P(AttnState), _P(AttnBwdWs), c_void_p, c_void_p, c_void_p,
-                                      c_void_p, C.c_float, C.c_int, _P(AttnGrads), c_void_p]),
+                                      c_void_p, C.c_float, C.c_int, _P(AttnGrads), c_void_p, c_void_p]),
     "gic_embedding_fwd": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, c_void_p]),
     "gic_embedding_bwd": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int, c_void_p]),
     "gic_disc_prepare": (C.c_int, [_P(DiscDims), _P(DiscParams), _P(DiscShadow), c_void_p]),

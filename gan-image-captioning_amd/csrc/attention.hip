@@ -77,18 +77,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
   // hp = W_h h_{t-1} was formed for all captions by one MFMA product (the launcher below): this block's row
   for (int j = tid; j < a.A; j += 256) hp_s[j] = a.hproj[(long)b * a.A + j];
   __syncthreads();
-  // e_i = w_a . tanh(fp_i + hp)  -- one wave per position
+  // e_i = w_a . tanh(fp_i + hp)  -- one wave per position, kFwdPos positions' loads in flight at once (a load -> tanh -> reduce loop
+  // pays one L2 round trip per position: 13 of them per wave at 49 positions)
   const TA* fp = (const TA*)a.fproj + (long)b * a.P * a.A;
-  for (int i = w; i < a.P; i += 4) {
-    float s = 0.f;
-    for (int j0 = lane * NV; j0 < a.A; j0 += 64 * NV) {
-      float v[NV];
-      Vec16<TA>::load(fp + (long)i * a.A + j0, v);
+  constexpr int kFwdPos = 4;
+  for (int i0 = w; i0 < a.P; i0 += 4 * kFwdPos) {
+    float s[kFwdPos];
 #pragma unroll
-      for (int q = 0; q < NV; ++q) s += a.w_a[j0 + q] * tanhf(v[q] + hp_s[j0 + q]);
+    for (int u = 0; u < kFwdPos; ++u) s[u] = 0.f;
+    for (int j0 = lane * NV; j0 < a.A; j0 += 64 * NV) {
+      float v[kFwdPos][NV];
+#pragma unroll
+      for (int u = 0; u < kFwdPos; ++u) {                              // unconditional loads (positions past P re-read the wave's first)
+        const int i = i0 + 4 * u < a.P ? i0 + 4 * u : i0;
+        Vec16<TA>::load(fp + (long)i * a.A + j0, v[u]);
+      }
+      float wa[NV], hp[NV];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) { wa[q] = a.w_a[j0 + q]; hp[q] = hp_s[j0 + q]; }
+#pragma unroll
+      for (int u = 0; u < kFwdPos; ++u)
+#pragma unroll
+        for (int q = 0; q < NV; ++q) s[u] += wa[q] * tanhf(v[u][q] + hp[q]);
     }
-    s = wave_sum(s);
-    if (lane == 0) e_s[i] = s;
+#pragma unroll
+    for (int u = 0; u < kFwdPos; ++u) {
+      const float t = wave_sum(s[u]);
+      if (lane == 0 && i0 + 4 * u < a.P) e_s[i0 + 4 * u] = t;
+    }
   }
   __syncthreads();
   // alpha = softmax over the P positions
@@ -112,13 +128,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
     float acc[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q) acc[q] = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < a.P; ++i) {
-      float v[NV];
-      Vec16<TA>::load(fm + (long)i * a.C + c0, v);
-      const float al = e_s[i];
+    // 8 positions' feature pieces in flight per thread (the positions of a caption are a dependent chain only through `acc`)
+    constexpr int kZ = 8;
+    for (int i0 = 0; i0 < a.P; i0 += kZ) {
+      float v[kZ][NV];
 #pragma unroll
-      for (int q = 0; q < NV; ++q) acc[q] += al * v[q];
+      for (int u = 0; u < kZ; ++u) Vec16<TA>::load(fm + (long)(i0 + u < a.P ? i0 + u : i0) * a.C + c0, v[u]);
+#pragma unroll
+      for (int u = 0; u < kZ; ++u) {
+        const float al = i0 + u < a.P ? e_s[i0 + u] : 0.f;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) acc[q] += al * v[u][q];
+      }
     }
     Vec16<TA>::store(zrow + c0, acc);
   }
@@ -135,6 +156,7 @@ struct AttnBwdArgs {
   float* dfproj;                     // [B, P, A] accumulated over the steps (zeroed by the caller)
   void* dhproj;                      // act [B, A] of this step (operand of the W_h weight gradient and of dh_{t-1} += dhp W_h)
   float* dwa_rows;                   // [B, A] accumulated over the steps (zeroed by the caller): d w_a per caption
+  float* dz_zero;                    // [B, C] or null: zeroed by attn_bwd after its last reader (the next step's split-K product adds into it)
   int P, A, H, C;
 };
 
@@ -186,20 +208,37 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a) {
     float hp[NV], wa[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q) { hp[q] = a.hproj[(long)b * a.A + j0 + q]; wa[q] = a.w_a[j0 + q]; }
-    for (int i = w; i < a.P; i += 4) {
-      float v[NV];
-      Vec16<TA>::load(fp + (long)i * a.A + j0, v);
-      const float de = de_s[i];
+    // kBwdPos positions per pass: their fp pieces and d fp rows (read-modify-write) are all requested before the first use
+    constexpr int kBwdPos = 4;
+    for (int i0 = w; i0 < a.P; i0 += 4 * kBwdPos) {
+      float v[kBwdPos][NV], d[kBwdPos][NV];
 #pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        const float th = tanhf(v[q] + hp[q]);
-        const float dpre = de * wa[q] * (1.f - th * th);
-        dfp[(long)i * a.A + j0 + q] += dpre;
-        dhp[q] += dpre;
-        dwa[q] += de * th;
+      for (int u = 0; u < kBwdPos; ++u) {
+        const int i = i0 + 4 * u < a.P ? i0 + 4 * u : i0;
+        Vec16<TA>::load(fp + (long)i * a.A + j0, v[u]);
+#pragma unroll
+        for (int q = 0; q < NV; q += 4) *(f32x4*)&d[u][q] = *(const f32x4*)(dfp + (long)i * a.A + j0 + q);
+      }
+#pragma unroll
+      for (int u = 0; u < kBwdPos; ++u) {
+        const int i = i0 + 4 * u;
+        if (i >= a.P) break;
+        const float de = de_s[i];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const float th = tanhf(v[u][q] + hp[q]);
+          const float dpre = de * wa[q] * (1.f - th * th);
+          d[u][q] += dpre;
+          dhp[q] += dpre;
+          dwa[q] += de * th;
+        }
+#pragma unroll
+        for (int q = 0; q < NV; q += 4) *(f32x4*)(dfp + (long)i * a.A + j0 + q) = *(const f32x4*)&d[u][q];
       }
     }
   }
+  if (a.dz_zero && blockIdx.x == 0)                        // dz of this step has been consumed by attn_dalpha (an earlier launch)
+    for (int c = tid * 4; c < a.C; c += 256 * 4) *(f32x4*)(a.dz_zero + (long)b * a.C + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < NV; ++q) { dhp_s[(w * 64 + lane) * NV + q] = dhp[q]; dwa_s[(w * 64 + lane) * NV + q] = dwa[q]; }
   __syncthreads();
@@ -235,7 +274,7 @@ int check_attn_dims(const gic_attn_dims* d, ACtx& c) {
 template <typename TA>
 int attn_fwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S, const gic_attn_state* st, const float* features,
                const void* fmap, const float* noise_u, uint64_t seed, float temperature, int pretrain, void* out, int64_t* ids,
-               const float* h0, const float* c0, hipStream_t stream) {
+               const float* h0, const float* c0, const float* t_dev, const uint64_t* seed_dev, hipStream_t stream) {
   const int B = c.B, L = c.L, V = c.V, E = c.E, H = c.H;
   const long ld = c.ldx();
   // slot 0: initial (h, c) -- zeros, or the caller's states (sample(features, fmap, states=(h0, c0))) -- and features -> x_0
@@ -262,12 +301,14 @@ int attn_fwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S
     set_last_error("attention kernel: cannot reserve %zu bytes of LDS", lds);
     return GIC_ERR_LAUNCH;
   }
+  // the per-step products below are split-K (f32 atomics into a zeroed C): ONE fill for all L steps instead of a zeroing launch per step
+  GIC_PROPAGATE(fill_zero(st->hproj, (size_t)L * B * c.A * sizeof(float), stream));
   for (int t = 0; t < L; ++t) {
     TA* xh_t = (TA*)st->xh + (long)t * B * ld;
     {  // hp [B, A] = h_{t-1} W_h^T for all captions: one product
       GemmDesc g;
       g.A = xh_t + c.din(); g.lda = ld; g.B = S->wh; g.ldb = H; g.C = st->hproj + (long)t * B * c.A; g.ldc = c.A;
-      g.M = B; g.N = c.A; g.K = H; g.in_dtype = c.dt; g.out_dtype = DT_F32;
+      g.M = B; g.N = c.A; g.K = H; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.c_zeroed = 1;
       GIC_PROPAGATE(gemm(g, stream));
     }
     AttnFwdArgs f;
@@ -288,6 +329,7 @@ int attn_fwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S
     v.h = xh_t + (long)B * ld + c.din(); v.ldh = ld; v.wout = S->wout; v.bias = P->b_out;
     v.u = noise_u ? noise_u + (long)t * B * V : nullptr;
     v.seed = seed; v.rng_stream = (uint64_t)t; v.temperature = temperature; v.pretrain = pretrain;
+    v.t_dev = t_dev; v.seed_dev = seed_dev;
     v.out = (TA*)out + (long)t * V; v.out_stride = (long)L * V;
     v.part_m = part_m + (long)t * B * nblk; v.part_s = part_s + (long)t * B * nblk; v.rowkey = rowkey + (long)t * B;
     v.nblk = nblk; v.B = B; v.V = V; v.H = H;
@@ -302,21 +344,25 @@ int attn_fwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S
 template <typename TA>
 int attn_bwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S, const gic_attn_state* st, const gic_attn_bwd_ws* ws,
                const void* fmap, const void* probs, const int64_t* ids, const void* d_out, float temperature, int pretrain,
-               const gic_attn_grads* G, hipStream_t stream) {
+               const gic_attn_grads* G, const float* t_dev, hipStream_t stream) {
   const int B = c.B, L = c.L, V = c.V, E = c.E, H = c.H, C = c.C, A = c.A;
   const long ld = c.ldx(), BL = (long)B * L;
-  GIC_PROPAGATE(decoder_output_bwd(c.dt, B, L, V, H, probs, d_out, temperature, nullptr, pretrain, ws->dlogits, S->wout, st->hout, ws->dhout,
+  GIC_PROPAGATE(decoder_output_bwd(c.dt, B, L, V, H, probs, d_out, temperature, t_dev, pretrain, ws->dlogits, S->wout, st->hout, ws->dhout,
                                    G->w_out, G->b_out, stream));
   GIC_PROPAGATE(fill_zero(ws->dc, (size_t)B * H * sizeof(float), stream));
   GIC_PROPAGATE(fill_zero(ws->dfproj, (size_t)B * c.P * A * sizeof(float), stream));
   GIC_PROPAGATE(fill_zero(ws->dwa_rows, (size_t)B * A * sizeof(float), stream));
+  // dz / dh_extra receive split-K products (f32 atomics) every step: zeroed here once, then re-zeroed by their last reader of the step
+  // (attn_bwd / the next lstm_bwd_step) instead of by a launch of their own
+  GIC_PROPAGATE(fill_zero(ws->dz, (size_t)B * C * sizeof(float), stream));
+  GIC_PROPAGATE(fill_zero(ws->dh_extra, (size_t)B * H * sizeof(float), stream));
   constexpr int kCols = 64 * Vec16<TA>::NV;                       // attention columns per attn_bwd block
   const size_t lds = (size_t)(c.P + 8 * kCols) * sizeof(float);
   const TA* wt = (const TA*)S->wcat_t;                      // [ldx, 4H]: rows 0..E-1 x, E..E+C-1 z, E+C.. h
   for (int t = L - 1; t >= 0; --t) {
     LstmBwdStepArgs a;
     a.dh_above = ws->dhout + (long)t * H; a.ld_above = (long)L * H;
-    if (t + 1 < L) { a.dg_next = (TA*)ws->dgates + (long)(t + 1) * B * 4 * H; a.w_rec = wt + (long)c.din() * 4 * H; a.dh_extra = ws->dh_extra; }
+    if (t + 1 < L) { a.dg_next = (TA*)ws->dgates + (long)(t + 1) * B * 4 * H; a.w_rec = wt + (long)c.din() * 4 * H; a.dh_extra = ws->dh_extra; a.zero_extra = 1; }
     a.gates = st->gates + (long)t * B * 4 * H;
     a.c_prev = st->c + (long)t * B * H; a.c_cur = st->c + (long)(t + 1) * B * H;
     a.dc_state = ws->dc; a.dgates = (TA*)ws->dgates + (long)t * B * 4 * H; a.B = B; a.H = H;
@@ -324,13 +370,14 @@ int attn_bwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S
     {  // dz_t [B, C] = dgates_t . W_z   (rows E .. E+C-1 of Wcat^T)
       GemmDesc g;
       g.A = a.dgates; g.lda = 4 * H; g.a_kc = 1; g.B = wt + (long)E * 4 * H; g.ldb = 4 * H; g.b_kc = 1;
-      g.C = ws->dz; g.ldc = C; g.M = B; g.N = C; g.K = 4 * H; g.in_dtype = c.dt; g.out_dtype = DT_F32;
+      g.C = ws->dz; g.ldc = C; g.M = B; g.N = C; g.K = 4 * H; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.c_zeroed = 1;
       GIC_PROPAGATE(gemm(g, stream));
     }
     AttnBwdArgs f;
     f.dz = ws->dz; f.alpha = st->alpha + (long)t * B * c.P; f.hproj = st->hproj + (long)t * B * A; f.fproj = st->fproj; f.fmap = fmap;
     f.w_a = P->w_a; f.dalpha = ws->dalpha; f.dfproj = ws->dfproj; f.dhproj = (TA*)ws->dhproj + (long)t * B * A; f.dwa_rows = ws->dwa_rows;
     f.P = c.P; f.A = A; f.H = H; f.C = C;
+    f.dz_zero = (C % 4 == 0) ? ws->dz : nullptr;
     hipLaunchKernelGGL((attn_dalpha_kernel<TA>), dim3((unsigned)cdiv((long)B * c.P, 4)), dim3(256), 0, stream, f, B);
     GIC_CHECK_LAUNCH("attn_dalpha");
     hipLaunchKernelGGL((attn_bwd_kernel<TA>), dim3((unsigned)cdiv(A, kCols), (unsigned)B), dim3(256), lds, stream, f);
@@ -338,7 +385,7 @@ int attn_bwd_t(const ACtx& c, const gic_attn_params* P, const gic_attn_shadow* S
     if (t > 0) {  // dh_{t-1} += dhp_t W_h  (consumed by the next lstm_bwd_step as dh_extra)
       GemmDesc g;
       g.A = f.dhproj; g.lda = A; g.a_kc = 1; g.B = S->wh; g.ldb = H; g.b_kc = 0; g.C = ws->dh_extra; g.ldc = H;
-      g.M = B; g.N = H; g.K = A; g.in_dtype = c.dt; g.out_dtype = DT_F32;
+      g.M = B; g.N = H; g.K = A; g.in_dtype = c.dt; g.out_dtype = DT_F32; g.c_zeroed = 1;
       GIC_PROPAGATE(gemm(g, stream));
     }
   }
@@ -408,22 +455,27 @@ int gic_attn_prepare(const gic_attn_dims* dims, const gic_attn_params* P, const 
 
 int gic_attn_sample_fwd(const gic_attn_dims* dims, const gic_attn_params* P, const gic_attn_shadow* S, const gic_attn_state* st,
                         const float* features, const void* fmap, const float* noise_u, uint64_t seed, float temperature, int pretrain,
-                        void* out, int64_t* ids, const float* h0, const float* c0, void* stream) {
+                        void* out, int64_t* ids, const float* h0, const float* c0, const gic_step_scalars* dev_scalars, int seed_slot,
+                        void* stream) {
   ACtx c;
   GIC_PROPAGATE(check_attn_dims(dims, c));
+  GIC_CHECK_ARG(!dev_scalars || (seed_slot >= 0 && seed_slot < GIC_STEP_SEEDS), "attn_sample_fwd: seed_slot out of range");
+  const float* t_dev = dev_scalars ? &dev_scalars->temperature : nullptr;
+  const uint64_t* seed_dev = dev_scalars ? &dev_scalars->seed[seed_slot] : nullptr;
   GIC_CHECK_ARG(P && S && st && features && fmap && out && ids, "attn_sample_fwd: null argument");
   GIC_CHECK_ARG(P->embed && P->b_out && P->b_f && P->w_a && S->wcat && S->bsum && S->wout && S->wf && S->wh, "attn_sample_fwd: null weights");
   GIC_CHECK_ARG(st->xh && st->gates && st->c && st->hout && st->part && st->fproj && st->alpha && st->hproj, "attn_sample_fwd: null state buffer");
   if (c.dt == DT_F32)
-    return attn_fwd_t<float>(c, P, S, st, features, fmap, noise_u, seed, temperature, pretrain, out, ids, h0, c0, (hipStream_t)stream);
-  return attn_fwd_t<bf16_t>(c, P, S, st, features, fmap, noise_u, seed, temperature, pretrain, out, ids, h0, c0, (hipStream_t)stream);
+    return attn_fwd_t<float>(c, P, S, st, features, fmap, noise_u, seed, temperature, pretrain, out, ids, h0, c0, t_dev, seed_dev, (hipStream_t)stream);
+  return attn_fwd_t<bf16_t>(c, P, S, st, features, fmap, noise_u, seed, temperature, pretrain, out, ids, h0, c0, t_dev, seed_dev, (hipStream_t)stream);
 }
 
 int gic_attn_sample_bwd(const gic_attn_dims* dims, const gic_attn_params* P, const gic_attn_shadow* S, const gic_attn_state* st,
                         const gic_attn_bwd_ws* ws, const void* fmap, const void* probs, const int64_t* ids, const void* d_out,
-                        float temperature, int pretrain, const gic_attn_grads* G, void* stream) {
+                        float temperature, int pretrain, const gic_attn_grads* G, const gic_step_scalars* dev_scalars, void* stream) {
   ACtx c;
   GIC_PROPAGATE(check_attn_dims(dims, c));
+  const float* t_dev = dev_scalars ? &dev_scalars->temperature : nullptr;
   GIC_CHECK_ARG(P && S && st && ws && fmap && probs && ids && d_out && G, "attn_sample_bwd: null argument");
   GIC_CHECK_ARG(S->wcat_t && S->wout && S->wh && P->w_a, "attn_sample_bwd: null weights");
   GIC_CHECK_ARG(ws->dlogits && ws->dhout && ws->dgates && ws->dc && ws->dz && ws->dalpha && ws->dh_extra && ws->dhproj && ws->dfproj && ws->dwa_rows && ws->dx &&
@@ -431,8 +483,8 @@ int gic_attn_sample_bwd(const gic_attn_dims* dims, const gic_attn_params* P, con
   GIC_CHECK_ARG(G->embed && G->w_ih && G->w_hh && G->b_ih && G->b_hh && G->w_out && G->b_out && G->w_f && G->b_f && G->w_h && G->w_a && G->features,
                 "attn_sample_bwd: null gradient buffer");
   if (c.dt == DT_F32)
-    return attn_bwd_t<float>(c, P, S, st, ws, fmap, probs, ids, d_out, temperature, pretrain, G, (hipStream_t)stream);
-  return attn_bwd_t<bf16_t>(c, P, S, st, ws, fmap, probs, ids, d_out, temperature, pretrain, G, (hipStream_t)stream);
+    return attn_bwd_t<float>(c, P, S, st, ws, fmap, probs, ids, d_out, temperature, pretrain, G, t_dev, (hipStream_t)stream);
+  return attn_bwd_t<bf16_t>(c, P, S, st, ws, fmap, probs, ids, d_out, temperature, pretrain, G, t_dev, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -76,6 +76,7 @@ struct SampleFinishArgs {
 struct LstmBwdStepArgs {
   const float* dh_above = nullptr; long ld_above = 0;   // f32 rows (top layer: dhout[b, t, :]) or null
   const float* dh_extra = nullptr;                      // f32 [B, H] added as is (attention decoder: gradient through W_h h_{t-1}) or null
+  int zero_extra = 0;                                   // != 0: dh_extra is zeroed behind the read (the next split-K product adds into it)
   const void* dg_next = nullptr;                        // act [B, 4H] dgates of step t+1, this layer (null at t = L-1)
   const void* w_rec = nullptr;                          // act rows j of wcat_t (+ din rows): [H][4H], W_hh^T
   const void* dg_up = nullptr;                          // act [B, 4H] dgates of step t, layer l+1 (null for the top layer)

@@ -623,7 +623,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(const LstmBwdStepArg
   float p_dh = 0.f, p_g[4] = {0.f, 0.f, 0.f, 0.f}, p_cc = 0.f, p_cp = 0.f, p_dc = 0.f;
   if (pok) {
     if (a.dh_above) p_dh = a.dh_above[(long)pb * a.ld_above + pj];
-    if (a.dh_extra) p_dh += a.dh_extra[pbh];
+    if (a.dh_extra) {
+      p_dh += a.dh_extra[pbh];
+      if (a.zero_extra) const_cast<float*>(a.dh_extra)[pbh] = 0.f;      // (each element has exactly one reader: this thread)
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) p_g[g] = a.gates[(long)pb * K + g * a.H + pj];
     p_cc = a.c_cur[pbh]; p_cp = a.c_prev[pbh]; p_dc = a.dc_state[pbh];

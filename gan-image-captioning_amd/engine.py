@@ -816,8 +816,9 @@ class AttnDecoderEngine:
         return s
 
     def sample_fwd(self, params, features, fmap, Lc: int, temperature: float, pretrain: bool = False, noise_u=None, seed: int = 0,
-                   state=None, out=None, ids=None, states=None):
-        """``state`` / ``out`` / ``ids``: caller-owned buffers (alloc_state; the fused step driver pre-allocates them).
+                   state=None, out=None, ids=None, states=None, dev_scalars=None, seed_slot: int = 0):
+        """``dev_scalars`` / ``seed_slot``: temperature and seed from device memory (StepScalarsBuffer).
+        ``state`` / ``out`` / ``ids``: caller-owned buffers (alloc_state; the fused step driver pre-allocates them).
         ``states`` = (h0, c0), each [1, B, H] or [B, H]: initial LSTM state (constants of the backward pass)."""
         self.check_params(params)
         require_gpu(features, fmap, noise_u)
@@ -849,7 +850,8 @@ class AttnDecoderEngine:
         L.check(L.load().gic_attn_sample_fwd(
             C.byref(self.dims(B, Lc)), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
             ptr(features.contiguous()), ptr(fmap), ptr(noise_u), int(seed) & (2 ** 64 - 1), float(temperature), int(bool(pretrain)),
-            ptr(out), ptr(ids), ptr(h0), ptr(c0), stream_ptr()), "gic_attn_sample_fwd")
+            ptr(out), ptr(ids), ptr(h0), ptr(c0), dev_scalars.ptr if dev_scalars is not None else None, int(seed_slot), stream_ptr()),
+            "gic_attn_sample_fwd")
         st["fmap"] = fmap
         return out, ids, st
 
@@ -870,7 +872,7 @@ class AttnDecoderEngine:
             "dx": torch.empty(Lc * B, self.E, device=dev, dtype=f32),
         }
 
-    def sample_bwd(self, params, st, out, ids, d_out, temperature: float, pretrain: bool = False, ws=None, grads=None):
+    def sample_bwd(self, params, st, out, ids, d_out, temperature: float, pretrain: bool = False, ws=None, grads=None, dev_scalars=None):
         """Returns [grads in NAMES order ..., d_features].  ``ws`` (alloc_bwd_ws) / ``grads`` (12 tensors): caller-owned buffers."""
         B, Lc = ids.shape
         dev = out.device
@@ -890,5 +892,6 @@ class AttnDecoderEngine:
         L.check(L.load().gic_attn_sample_bwd(
             C.byref(self.dims(B, Lc)), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)), C.byref(self._state_struct(st)),
             C.byref(w), ptr(st["fmap"]), ptr(out), ptr(ids), ptr(d_out), float(temperature), int(bool(pretrain)),
-            C.byref(self._pstruct(grads[:-1], L.AttnGrads, grads[-1])), stream_ptr()), "gic_attn_sample_bwd")
+            C.byref(self._pstruct(grads[:-1], L.AttnGrads, grads[-1])), dev_scalars.ptr if dev_scalars is not None else None, stream_ptr()),
+            "gic_attn_sample_bwd")
         return grads

@@ -35,8 +35,11 @@ class FusedAdvStep:
         self._disc_grads = None
         self.overlap = not os.environ.get("GIC_NO_STREAM_OVERLAP")
         self.trace = None
-        # (the attention kernels take temperature / seed by value: that step stays eager launches)
-        self.use_graph = not (os.environ.get("GIC_NO_STEP_GRAPH") or os.environ.get("GIC_NO_GRAPH")) and not self.attn
+        self.use_graph = not (os.environ.get("GIC_NO_STEP_GRAPH") or os.environ.get("GIC_NO_GRAPH"))
+        if self.attn and not os.environ.get("GIC_STEP_GRAPH_ATTN"):
+            # the attention step replays as graphs too (host enqueue 2.10 -> 0.43 ms per step) but measured 3.87 ms per step against
+            # 3.74 for eager launches at cfg4 (same box, back to back): eager is the default there, GIC_STEP_GRAPH_ATTN=1 opts in
+            self.use_graph = False
         self._graphs: Dict[tuple, dict] = {}
         self._warm: set = set()
 
@@ -184,7 +187,7 @@ class FusedAdvStep:
         # it finished only after the whole trunk pass -- so it stays on the main stream)
         if self.attn:
             probs, ids, dst = self.dec.sample_fwd(gparams, feats, fmap, L, T, False, noise_u, seeds[3], state=buf["dec_state"],
-                                                  out=buf["probs"], ids=buf["ids"])
+                                                  out=buf["probs"], ids=buf["ids"], dev_scalars=scal, seed_slot=3)
         else:
             probs, ids, dst = self.dec.sample_fwd(gparams, feats, L, T, False, noise_u, seeds[3], state=buf["dec_state"],
                                                   out=buf["probs"], ids=buf["ids"], dev_scalars=scal, seed_slot=3)
@@ -218,7 +221,8 @@ class FusedAdvStep:
                 self._mark("D(gen) input-grad done [s_gen]", s_gen)
                 early = self._early_bucket() if (self.reducer is not None and not self.attn) else None
                 if self.attn:
-                    self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"], grads=g_grads + [buf["d_feat"]])
+                    self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"], grads=g_grads + [buf["d_feat"]],
+                                        dev_scalars=scal)
                 elif early is None:
                     self.dec.sample_bwd(gparams, dst, probs, ids, buf["d_probs"], T, False, ws=buf["dec_ws"],
                                         grads=g_grads + [buf["d_feat"]], dev_scalars=scal)
@@ -314,8 +318,13 @@ class FusedAdvStep:
                 ctx["feats"] = gen.encoder.forward_fused(None, True, trunk_feats=buf["trunk_in"])
             else:
                 ctx["feats"] = engine.embedding_fwd(gparams[0], buf["ones"])
-            ctx["probs"], ctx["ids"], ctx["dst"] = self.dec.sample_fwd(gparams, ctx["feats"], L, 0.0, False, None, 0, state=buf["dec_state"],
-                                                                      out=buf["probs"], ids=buf["ids"], dev_scalars=scal, seed_slot=3)
+            if self.attn:
+                ctx["probs"], ctx["ids"], ctx["dst"] = self.dec.sample_fwd(gparams, ctx["feats"], buf["fmap_in"], L, 0.0, False, None, 0,
+                                                                          state=buf["dec_state"], out=buf["probs"], ids=buf["ids"],
+                                                                          dev_scalars=scal, seed_slot=3)
+            else:
+                ctx["probs"], ctx["ids"], ctx["dst"] = self.dec.sample_fwd(gparams, ctx["feats"], L, 0.0, False, None, 0, state=buf["dec_state"],
+                                                                          out=buf["probs"], ids=buf["ids"], dev_scalars=scal, seed_slot=3)
 
         def d_fake():                     # main, behind D(real): D(fake), D(gen) (training.py:163-164), losses
             self.den.fwd(dparams, ctx["probs"], None, True, None, 0, state=buf["st_fake"], logits=lg[1], dev_scalars=scal, seed_slot=1)
@@ -332,8 +341,12 @@ class FusedAdvStep:
         def g_bwd():                      # s_gen: decoder BPTT + weight gradients, encoder head (training.py:169 minus the step)
             if a.adv_loss_type == "rsgan":
                 return
-            self.dec.sample_bwd(gparams, ctx["dst"], ctx["probs"], ctx["ids"], buf["d_probs"], 0.0, False, ws=buf["dec_ws"],
-                                grads=g_grads + [buf["d_feat"]], dev_scalars=scal)
+            if self.attn:
+                self.dec.sample_bwd(gparams, ctx["dst"], ctx["probs"], ctx["ids"], buf["d_probs"], 0.0, False, ws=buf["dec_ws"],
+                                    grads=g_grads + [buf["d_feat"]], dev_scalars=scal)
+            else:
+                self.dec.sample_bwd(gparams, ctx["dst"], ctx["probs"], ctx["ids"], buf["d_probs"], 0.0, False, ws=buf["dec_ws"],
+                                    grads=g_grads + [buf["d_feat"]], dev_scalars=scal)
             if self.cgan:
                 gen.encoder.backward_fused(buf["d_feat"])
             else:
@@ -367,6 +380,8 @@ class FusedAdvStep:
             buf["scal"] = engine.StepScalarsBuffer(dev)
             if self.cgan:
                 buf["trunk_in"] = torch.empty(B, self.gen.encoder.resnet.out_features, device=dev, dtype=self.dec.act)
+            if self.attn:
+                buf["fmap_in"] = torch.empty(B, self.dec.P, self.dec.C, device=dev, dtype=self.dec.act)
         scal = buf["scal"]
         key = self._graph_key(B, L)
         g = self._graphs.get(key)
@@ -405,7 +420,11 @@ class FusedAdvStep:
                 run("d_real", s_real)
                 ev_real = s_real.record_event()
             if self.cgan:
-                buf["trunk_in"].copy_(self._take_and_prefetch(images, True, main, ev_start, next_images, next_train))
+                tf = self._take_and_prefetch(images, True, main, ev_start, next_images, next_train)
+                if self.attn:
+                    buf["fmap_in"].copy_(tf[1].view(B, self.dec.P, self.dec.C))
+                    tf = tf[0]
+                buf["trunk_in"].copy_(tf)
             run("rollout", main)
             main.wait_event(ev_real)
             run("d_fake", main)

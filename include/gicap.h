@@ -294,14 +294,15 @@ int gic_attn_prepare(const gic_attn_dims* dims, const gic_attn_params* params, c
  * flows into it: the trunk is frozen, generator.py:21).  noise_u / seed / temperature / pretrain / out / ids as
  * gic_decoder_sample_fwd.  V % 4 == 0 and E, H, C, A % 8 == 0.  h0 / c0: f32 [B, H] initial hidden / cell state (the `states`
  * argument of Decoder.sample's signature, generator.py:55,61) or NULL = zeros; they are constants of the backward pass (no
- * gradient is returned for them). */
+ * gradient is returned for them).  dev_scalars / seed_slot: temperature and seed from device memory (gic_step_scalars). */
 int gic_attn_sample_fwd(const gic_attn_dims* dims, const gic_attn_params* params, const gic_attn_shadow* shadow,
                         const gic_attn_state* state, const float* features, const void* fmap, const float* noise_u, uint64_t seed,
-                        float temperature, int pretrain, void* out, int64_t* ids, const float* h0, const float* c0, void* stream);
+                        float temperature, int pretrain, void* out, int64_t* ids, const float* h0, const float* c0,
+                        const gic_step_scalars* dev_scalars, int seed_slot, void* stream);
 int gic_attn_sample_bwd(const gic_attn_dims* dims, const gic_attn_params* params, const gic_attn_shadow* shadow,
                         const gic_attn_state* state, const gic_attn_bwd_ws* ws, const void* fmap, const void* probs,
                         const int64_t* ids, const void* d_out, float temperature, int pretrain, const gic_attn_grads* grads,
-                        void* stream);
+                        const gic_step_scalars* dev_scalars, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Discriminator.forward (src/discriminator.py:34-62) forward + backward.

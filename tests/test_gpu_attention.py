@@ -93,7 +93,7 @@ def test_attention_adversarial_and_pretrain_steps_through_the_instructor():
                         attn_dim=24, compute_dtype="fp32", image_size=64, device="cuda", log_file=None, model_dir=None, save_dir=None)
     inst = GANInstructor(args, None, None)
     dev = args.device
-    assert args.step_impl == "fused" and inst.fused.attn and not inst.fused.use_graph      # round 3: the fused driver takes the attention decoder
+    assert args.step_impl == "fused" and inst.fused.attn      # round 3: the fused driver (and its step graphs) take the attention decoder
     g = torch.Generator().manual_seed(3)
     images = torch.randn(B, 3, 64, 64, generator=g).to(dev)
     caps = O.make_captions(B, L, V, g).to(dev)
@@ -263,3 +263,30 @@ def test_cfg4_composed_step_bf16_vs_oracle():
     lim = lambda k: (8e-2 if k.startswith("d_grad") else 2.5e-1 if ".attn." in k else 2e-1 if "encoder." in k else 1.3e-1)      # noqa: E731
     bad = [(k, v, lim(k)) for k, v in report.items() if k.startswith(("g_grad_rel_l2/", "d_grad_rel_l2/")) and not v < lim(k)]
     assert not bad, bad
+
+
+def test_attention_decoder_takes_initial_states():
+    """AttnDecoder.sample(features, fmap, states=(h0, c0)) -- the `states` argument of the reference's Decoder.sample signature
+    (src/generator.py:55,61) -- against the oracle started from the same states (fp32: ids exact, probabilities 1e-4); the states are
+    constants of the backward pass; zero states reproduce the default call."""
+    from gan_image_captioning_amd import engine as E
+    shape = (5, 4, 64, 16, 32, 40, 9, 24)
+    B, L, V, Em, H, C, P, At = shape
+    dev = torch.device("cuda:0")
+    gp, feats, fmap, us, _ = _problem(*shape, seed=23)
+    g = torch.Generator().manual_seed(24)
+    h0, c0 = torch.randn(1, B, H, generator=g) * 0.5, torch.randn(1, B, H, generator=g) * 0.5
+    T = 1.3
+    eng = E.AttnDecoderEngine(V, Em, H, C, P, At, 0)
+    params = [gp[n].to(dev).contiguous() for n in NAMES]
+    u = torch.stack(us).to(dev)
+    out, ids, _ = eng.sample_fwd(params, feats.to(dev), fmap.to(dev), L, T, noise_u=u, states=(h0.to(dev), c0.to(dev)))
+    torch.cuda.synchronize()
+    want, ids_ref, _ = A.attn_decoder_sample(gp, feats, fmap, L, T, us, states=(h0, c0))
+    assert torch.equal(ids.cpu(), ids_ref)
+    close(out, want, rtol=1e-4, atol_scale=1e-6, what="probs with initial states")
+    base, ids_b, _ = eng.sample_fwd(params, feats.to(dev), fmap.to(dev), L, T, noise_u=u)
+    zero, ids_z, _ = eng.sample_fwd(params, feats.to(dev), fmap.to(dev), L, T, noise_u=u, states=(torch.zeros(1, B, H, device=dev), torch.zeros(1, B, H, device=dev)))
+    torch.cuda.synchronize()
+    assert torch.equal(ids_b, ids_z) and torch.equal(base, zero)
+    assert not torch.equal(out, base)                               # the states matter

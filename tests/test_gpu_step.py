@@ -420,3 +420,51 @@ def test_step_graph_replay_equals_eager_launches(monkeypatch):
     torch.testing.assert_close(e["disc"], r["disc"], rtol=1e-4, atol=5e-6)
     torch.testing.assert_close(e["gen"], r["gen"], rtol=1e-4, atol=5e-6)
     assert not torch.equal(e["losses"][1], e["losses"][3])               # the steps differ from each other (weights, temperature, noise)
+
+
+def test_attention_step_graph_replay_equals_eager_launches(monkeypatch):
+    """The same check for the attention decoder's step (cfg4), whose graphs are opt-in (GIC_STEP_GRAPH_ATTN=1: measured slightly slower
+    than eager launches there): ResNet-18 trunk at 64x64, fp32, device noise from the same seed sequence, four steps."""
+    from gan_image_captioning_amd.args import default_args
+    from gan_image_captioning_amd.generator import SEEDS
+    from gan_image_captioning_amd.training import GANInstructor
+    from oracle import cpu_step as O
+    B, L, V = 8, 6, 64
+    g = torch.Generator().manual_seed(77)
+    images = torch.randn(B, 3, 64, 64, generator=g)
+    caps = O.make_captions(B, L, V, g)
+    res = {}
+    state = None
+    for mode in ("eager", "graph"):
+        if mode == "graph":
+            monkeypatch.setenv("GIC_STEP_GRAPH_ATTN", "1")
+        else:
+            monkeypatch.delenv("GIC_STEP_GRAPH_ATTN", raising=False)
+        torch.manual_seed(5)
+        args = default_args(vocab_size=V, gen_embed_dim=16, gen_hidden_dim=32, conditional_gan=1, encoder_arch="resnet18", decoder="attention",
+                            attn_dim=24, compute_dtype="fp32", image_size=64, adv_train_batch_size=B, device="cuda", log_file=None,
+                            model_dir=None, save_dir=None)
+        inst = GANInstructor(args, None, None)
+        assert inst.fused.use_graph == (mode == "graph")
+        if state is None:
+            state = ({k: v.clone() for k, v in inst.gen.state_dict().items()}, {k: v.clone() for k, v in inst.disc.state_dict().items()})
+        else:
+            inst.gen.load_state_dict(state[0]); inst.disc.load_state_dict(state[1])
+            from gan_image_captioning_amd import engine
+            engine.bump_param_epoch()
+        inst.gen.train(); inst.disc.train()
+        dev = args.device
+        im, cp = images.to(dev), caps.to(dev)
+        SEEDS.reset(4321)
+        losses = []
+        for k in range(4):
+            inst.gen.decoder.temperature = 1.0 + 0.3 * k
+            losses.append(inst.fused(im, cp, L, True)["losses"].clone())
+        torch.cuda.synchronize()
+        if mode == "graph":
+            assert len(inst.fused._graphs) == 1
+        res[mode] = (torch.stack(losses).cpu(), inst.gen_arena.flat.cpu().clone(), inst.disc_arena.flat.cpu().clone())
+    # (the trunk's BatchNorm sums are f32 atomics: the features differ in the last bits from run to run)
+    torch.testing.assert_close(res["eager"][0], res["graph"][0], rtol=2e-4, atol=1e-6)
+    torch.testing.assert_close(res["eager"][2], res["graph"][2], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(res["eager"][1], res["graph"][1], rtol=1e-3, atol=2e-5)
