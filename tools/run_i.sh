@@ -5,7 +5,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/r3_prof_cfg4 -o run -
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
 import csv, glob
-for wl, steps in (("cfg5", 9), ("cfg4", 9)):
+for wl, steps in (("cfg4", 9), ("cfg5", 9)):
     f = glob.glob(f"gpurun_out/r3_prof_{wl}/**/*kernel_stats.csv", recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
