@@ -140,6 +140,8 @@ _SIGNATURES = {
     "gic_decoder_forward_tf": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), _P(DecoderState), c_void_p, c_void_p,
                                          c_void_p, C.c_int, c_void_p, C.c_uint64, C.c_float, C.c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p]),
+    "gic_decoder_forward_tf_bwd": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), _P(DecoderState), _P(DecoderBwdWs),
+                                             c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, C.c_float, C.c_int, _P(DecoderGrads), c_void_p]),
     "gic_decoder_sample_bwd": (C.c_int, [_P(DecoderDims), _P(DecoderParams), _P(DecoderShadow), _P(DecoderState),
                                          _P(DecoderBwdWs), c_void_p, c_void_p, c_void_p, C.c_float, C.c_int,
                                          _P(DecoderGrads), C.c_int, c_void_p, c_void_p]),
@@ -183,7 +185,7 @@ _SIGNATURES = {
                                 C.c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
-ABI_VERSION = 3               # GIC_ABI_VERSION of include/gicap.h
+ABI_VERSION = 4               # GIC_ABI_VERSION of include/gicap.h
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 

@@ -661,7 +661,7 @@ int sample_bwd_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
   return GIC_OK;
 }
 
-__global__ void embed_scatter_time_kernel(const float* __restrict__ dxh0, long ld, const int64_t* __restrict__ ids,
+__global__ void embed_scatter_time_kernel(const float* __restrict__ dxh0, long ld, const int64_t* __restrict__ ids, long ids_stride,
                                           float* __restrict__ dw, int B, int L, int E, int V) {
   const long total = (long)(L - 1) * B * E;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -669,7 +669,7 @@ __global__ void embed_scatter_time_kernel(const float* __restrict__ dxh0, long l
     const long r = i / E;
     const int b = (int)(r % B);
     const int t = (int)(r / B) + 1;
-    long id = ids[(long)b * L + (t - 1)];
+    long id = ids[(long)b * ids_stride + (t - 1)];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
     atomicAdd(&dw[id * E + e], dxh0[((long)t * B + b) * ld + e]);
   }
@@ -716,13 +716,15 @@ int decoder_output_bwd(int dt, int B, int L, int V, int H, const void* probs, co
   return colsum(dlog, dt, V, BL, V, d_bout, nullptr, 0, stream);
 }
 
-// d_embed[ids[b, t-1]] += dx_t (t >= 1) over a zeroed table (generator.py:75: the index is detached); dx rows at dx + (t*B + b)*ld
-int embed_scatter_time(const float* dx, long ld, const int64_t* ids, float* d_embed, int B, int L, int E, int V, hipStream_t stream) {
+// d_embed[ids[b, t-1]] += dx_t (t >= 1) over a zeroed table (generator.py:75: the index is detached); dx rows at dx + (t*B + b)*ld,
+// ids rows ids_stride apart (0: L)
+int embed_scatter_time(const float* dx, long ld, const int64_t* ids, float* d_embed, int B, int L, int E, int V, hipStream_t stream, long ids_stride) {
+  if (ids_stride <= 0) ids_stride = L;
   GIC_PROPAGATE(fill_zero(d_embed, (size_t)V * E * sizeof(float), stream));
   if (L > 1) {
     const long total = (long)(L - 1) * B * E;
     const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-    hipLaunchKernelGGL(embed_scatter_time_kernel, dim3(grid), dim3(256), 0, stream, dx, ld, ids, d_embed, B, L, E, V);
+    hipLaunchKernelGGL(embed_scatter_time_kernel, dim3(grid), dim3(256), 0, stream, dx, ld, ids, ids_stride, d_embed, B, L, E, V);
     GIC_CHECK_LAUNCH("embed_scatter_time");
   }
   return GIC_OK;
@@ -753,11 +755,13 @@ template <typename TA>
 __global__ void lstm_pointwise_tf_kernel(const float* __restrict__ gpre, const float* __restrict__ c_prev, const TA* __restrict__ h_prev,
                                          long ld_prev, float* __restrict__ c_new, TA* __restrict__ h_next, long ld_next,
                                          TA* __restrict__ h_up, long ld_up, TA* __restrict__ h_out, long ld_out,
-                                         const int32_t* __restrict__ lengths, int t, int B, int H) {
+                                         const int32_t* __restrict__ lengths, int t, int B, int H, float* __restrict__ gates_out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * H) return;
   const int b = idx / H, j = idx % H;
+  float* go = gates_out ? gates_out + (long)b * 4 * H + j : nullptr;   // saved for gic_decoder_forward_tf_bwd, laid out as lstm_step saves them
   if (t >= lengths[b]) {
+    if (go) { go[0] = 0.f; go[H] = 0.f; go[2 * H] = 0.f; go[3 * H] = 0.f; }   // never weighted by a non-zero gradient: finite is all that matters
     c_new[idx] = c_prev[idx];
     const TA hp = h_prev[(long)b * ld_prev + j];
     h_next[(long)b * ld_next + j] = hp;
@@ -772,10 +776,21 @@ __global__ void lstm_pointwise_tf_kernel(const float* __restrict__ gpre, const f
   const float o_ = sigmoidf_(g[3 * H + j]);
   const float c = f_ * c_prev[idx] + i_ * g_;
   const float h = o_ * tanhf(c);
+  if (go) { go[0] = i_; go[H] = f_; go[2 * H] = g_; go[3 * H] = o_; }
   c_new[idx] = c;
   h_next[(long)b * ld_next + j] = from_f32<TA>(h);
   if (h_up) h_up[(long)b * ld_up + j] = from_f32<TA>(h);
   if (h_out) h_out[(long)b * ld_out + j] = from_f32<TA>(h);
+}
+
+// d_hout [B, Tmax, H]: rows past their sequence's length are pad_packed_sequence's constant zeros (generator.py:45): no gradient reaches the LSTM
+__global__ void zero_past_length_kernel(float* __restrict__ dhout, const int32_t* __restrict__ lengths, int B, int Tmax, int H) {
+  const long total = (long)B * Tmax * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / H;
+    const int b = (int)(r / Tmax), t = (int)(r % Tmax);
+    if (t >= lengths[b]) dhout[i] = 0.f;
+  }
 }
 
 template <typename TA>
@@ -810,7 +825,7 @@ int forward_tf_t(const Ctx& c, const gic_decoder_params* P, const gic_decoder_sh
       hipLaunchKernelGGL((lstm_pointwise_tf_kernel<TA>), dim3(pw_grid), dim3(256), 0, stream, (const float*)st->gpre,
                          (const float*)(st->c[l] + (long)t * B * H), (const TA*)(xh_t + c.din(l)), ld,
                          st->c[l] + (long)(t + 1) * B * H, xh_n + c.din(l), ld, h_up, h_up ? c.ldx(l + 1) : 0, h_out, (long)Tmax * H,
-                         lengths, t, B, H);
+                         lengths, t, B, H, st->gates[l] ? st->gates[l] + (long)t * B * 4 * H : nullptr);
       GIC_CHECK_LAUNCH("lstm_pointwise_tf");
     }
   }
@@ -852,6 +867,39 @@ int gic_decoder_forward_tf(const gic_decoder_dims* dims, const gic_decoder_param
                                h_n, c_n, (hipStream_t)stream);
   return forward_tf_t<bf16_t>(c, P, S, st, features, caps, lengths, Tmax, noise_u, seed, temperature, pretrain, logits_ws, ids_ws, out,
                               h_n, c_n, (hipStream_t)stream);
+}
+
+int gic_decoder_forward_tf_bwd(const gic_decoder_dims* dims, const gic_decoder_params* P, const gic_decoder_shadow* S,
+                               const gic_decoder_state* st, const gic_decoder_bwd_ws* ws, const void* pred, const int64_t* caps,
+                               const int32_t* lengths, int Tmax, const void* d_pred, float temperature, int pretrain,
+                               const gic_decoder_grads* G, void* stream_) {
+  Ctx c;
+  GIC_PROPAGATE(check_dims(dims, c));
+  GIC_CHECK_ARG(P && S && st && ws && pred && lengths && d_pred && G, "decoder_forward_tf_bwd: null argument");
+  GIC_CHECK_ARG(c.L == 1 || caps, "decoder_forward_tf_bwd: caps is null");
+  GIC_CHECK_ARG(Tmax >= 1 && Tmax <= c.L, "decoder_forward_tf_bwd: Tmax must be in 1..L (= caption length + 1)");
+  GIC_CHECK_ARG(ws->dlogits && ws->dhout && st->hout && S->wout && G->embed && G->w_out && G->b_out && G->features, "decoder_forward_tf_bwd: null buffer");
+  for (int l = 0; l < c.NL; ++l)
+    GIC_CHECK_ARG(st->xh[l] && st->c[l] && st->gates[l] && ws->dgates[l] && ws->dxh[l] && ws->dc[l] && G->w_ih[l] && G->w_hh[l] && G->b_ih[l] && G->b_hh[l],
+                  "decoder_forward_tf_bwd: null layer %d buffer (the forward call must have been given state->gates)", l);
+  hipStream_t stream = (hipStream_t)stream_;
+  const int T = c.L;
+  // the saved state and every [B, Tmax, .] tensor are laid out for Tmax steps: run the sampled path's backward on that view
+  c.L = Tmax;
+  GIC_PROPAGATE(decoder_output_bwd(c.dt, c.B, Tmax, c.V, c.H, pred, d_pred, temperature, nullptr, pretrain, ws->dlogits, S->wout, st->hout, ws->dhout,
+                                   G->w_out, G->b_out, stream));
+  {
+    const long total = (long)c.B * Tmax * c.H;
+    hipLaunchKernelGGL(zero_past_length_kernel, dim3((unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0, stream,
+                       ws->dhout, lengths, c.B, Tmax, c.H);
+    GIC_CHECK_LAUNCH("zero_past_length");
+  }
+  // caps stands in for the sampled ids (the input of step t is embed(caps[b, t-1])); sample_bwd_t itself never reads them
+  const int s = (c.dt == DT_F32)
+                    ? sample_bwd_t<float>(c, P, S, st, ws, pred, caps, d_pred, temperature, nullptr, pretrain, G, GIC_DECODER_BWD_RECURRENT, stream)
+                    : sample_bwd_t<bf16_t>(c, P, S, st, ws, pred, caps, d_pred, temperature, nullptr, pretrain, G, GIC_DECODER_BWD_RECURRENT, stream);
+  GIC_PROPAGATE(s);
+  return embed_scatter_time((const float*)ws->dxh[0], c.ldx(0), caps, G->embed, c.B, Tmax, c.E, c.V, stream, T - 1);
 }
 
 void gic_debug_decoder_step(int v) { decoder_step_debug(v); }

@@ -21,6 +21,6 @@ int transpose2d(const void* src, void* dst, int dtype, long rows, long cols, hip
 // decoder.hip internals shared with attention.hip
 int decoder_output_bwd(int dt, int B, int L, int V, int H, const void* probs, const void* d_out, float temperature, const float* t_dev, int pretrain,
                        void* dlogits_ws, const void* wout, const void* hout, float* dhout, float* d_wout, float* d_bout, hipStream_t stream);
-int embed_scatter_time(const float* dx, long ld, const int64_t* ids, float* d_embed, int B, int L, int E, int V, hipStream_t stream);
+int embed_scatter_time(const float* dx, long ld, const int64_t* ids, float* d_embed, int B, int L, int E, int V, hipStream_t stream, long ids_stride = 0);
 
 }  // namespace gic

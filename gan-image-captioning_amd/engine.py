@@ -417,9 +417,9 @@ class DecoderEngine:
         return (None if ids_only else out), ids, st
 
     def forward_tf(self, params, features: torch.Tensor, caps: torch.Tensor, lengths, temperature: float, pretrain: bool = False,
-                   noise_u: Optional[torch.Tensor] = None, seed: int = 0):
-        """gic_decoder_forward_tf: Decoder.forward (teacher forcing, generator.py:39-53), forward only.
-        Returns (pred act [B, max(lengths), V], (h_n, c_n) f32 [NL, B, H])."""
+                   noise_u: Optional[torch.Tensor] = None, seed: int = 0, keep_state: bool = False):
+        """gic_decoder_forward_tf: Decoder.forward (teacher forcing, generator.py:39-53).
+        Returns (pred act [B, max(lengths), V], (h_n, c_n) f32 [NL, B, H]); with ``keep_state`` also what ``forward_tf_bwd`` needs."""
         self.check_params(params)
         require_gpu(features, caps, noise_u)
         B, Lc = caps.shape
@@ -447,7 +447,34 @@ class DecoderEngine:
             ptr(features.contiguous().float()), ptr(caps.contiguous()), ptr(len_dev), Tmax,
             ptr(noise_u.contiguous().float()) if noise_u is not None else None, int(seed) & (2 ** 64 - 1), float(temperature),
             int(bool(pretrain)), ptr(logits_ws), ptr(ids_ws), ptr(out), ptr(h_n), ptr(c_n), stream_ptr()), "gic_decoder_forward_tf")
+        if keep_state:
+            return out, (h_n, c_n), {"st": st, "caps": caps.contiguous(), "len_dev": len_dev, "Tmax": Tmax, "T": T}
         return out, (h_n, c_n)
+
+    def forward_tf_bwd(self, params, saved, pred: torch.Tensor, d_pred: torch.Tensor, temperature: float, pretrain: bool = False,
+                       ws=None, grads=None) -> List[torch.Tensor]:
+        """gic_decoder_forward_tf_bwd: gradients of a loss on ``pred`` of the ``forward_tf(..., keep_state=True)`` call that returned
+        ``saved``; the list is ordered as ``sample_bwd``'s (parameters, then d features)."""
+        B, Tmax, dev = pred.shape[0], saved["Tmax"], pred.device
+        if tuple(d_pred.shape) != tuple(pred.shape):
+            raise ValueError("d_pred must have pred's shape")
+        if d_pred.dtype != self.act:
+            d_pred = self._cast_like(d_pred)
+        d_pred = d_pred.contiguous()
+        self.prepare(params)
+        ws = ws if ws is not None else self.alloc_bwd_ws(B, Tmax, dev)
+        grads = grads if grads is not None else self.alloc_grads(params, B)
+        w = L.DecoderBwdWs()
+        w.dlogits, w.dhout = ptr(ws["dlogits"]), ptr(ws["dhout"])
+        w.dgates = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in ws["dgates"]])
+        w.dxh = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in ws["dxh"]])
+        w.dc = _arr(C.c_void_p, L.MAX_LAYERS, [ptr(t) for t in ws["dc"]])
+        L.check(L.load().gic_decoder_forward_tf_bwd(
+            C.byref(self.dims(B, saved["T"])), C.byref(self._pstruct(params)), C.byref(self._shadow_struct(params)),
+            C.byref(self._state_struct(saved["st"])), C.byref(w), ptr(pred), ptr(saved["caps"]), ptr(saved["len_dev"]), Tmax, ptr(d_pred),
+            float(temperature), int(bool(pretrain)), C.byref(self._pstruct(grads[:-1], L.DecoderGrads, grads[-1])), stream_ptr()),
+            "gic_decoder_forward_tf_bwd")
+        return grads
 
     def sample_bwd(self, params, st, out: torch.Tensor, ids: torch.Tensor, d_out: torch.Tensor, temperature: float,
                    pretrain: bool = False, ws=None, grads=None, phases: int = 3, dev_scalars=None) -> List[torch.Tensor]:

@@ -129,6 +129,27 @@ class _SampleFn(torch.autograd.Function):
         return (None, None, None, None, None, None, d_h0, d_c0, grads[-1], *grads[:-1])
 
 
+class _ForwardTfFn(torch.autograd.Function):
+    """Decoder.forward with autograd (generator.py:39-53): gic_decoder_forward_tf / gic_decoder_forward_tf_bwd."""
+
+    @staticmethod
+    def forward(ctx, eng, temperature, pretrain, caps, lengths, noise_u, seed, features, *params):
+        dparams = [p.detach() for p in params]
+        pred, (h_n, c_n), saved = eng.forward_tf(dparams, features.detach().float(), caps, lengths, temperature, pretrain, noise_u, seed,
+                                                 keep_state=True)
+        ctx.eng, ctx.temperature, ctx.pretrain, ctx.saved, ctx.dparams = eng, temperature, pretrain, saved, dparams
+        ctx.save_for_backward(pred)
+        ctx.mark_non_differentiable(h_n, c_n)
+        return pred, h_n, c_n
+
+    @staticmethod
+    def backward(ctx, d_pred, _d_h, _d_c):
+        (pred,) = ctx.saved_tensors
+        grads = ctx.eng.forward_tf_bwd(ctx.dparams, ctx.saved, pred, d_pred, ctx.temperature, ctx.pretrain)
+        ctx.saved = None
+        return (None, None, None, None, None, None, None, grads[-1], *grads[:-1])
+
+
 class Decoder(nn.Module):
     """Embedding + LSTM + Linear caption decoder (generator.py:27-96)."""
 
@@ -167,14 +188,19 @@ class Decoder(nn.Module):
     def forward(self, features, caps, lengths, pretrain=False, noise_u=None):
         """Teacher-forced decode (generator.py:39-53): inputs [features ; embed(caps)] packed with ``lengths``; returns
         (pred [B, max(lengths), V], (h_n, c_n)) with pred = logits (pretrain) or softmax((logits + gumbel) * temperature).
-        Dead on the reference's training path (training.py never calls it), kept for the module surface: forward only, the
-        results carry no autograd graph (use ``sample`` for anything that is trained through).  ``noise_u`` [B, max(lengths), V]
+        Dead on the reference's training path (training.py never calls it), kept for the module surface.  Gradients flow through
+        ``pred`` to the decoder parameters and ``features`` (padded positions reach the projection's bias only, as
+        pad_packed_sequence's zeros do); the returned hidden state is not differentiated.  ``noise_u`` [B, max(lengths), V]
         replaces the device draw (parity runs)."""
-        with torch.no_grad():
-            seed = 0 if noise_u is not None else SEEDS.next()
-            pred, hidden = self.engine().forward_tf([p.detach() for p in self.param_list()], features, caps, lengths,
-                                                    float(self.temperature), bool(pretrain), noise_u, seed)
-        return pred, hidden
+        seed = 0 if noise_u is not None else SEEDS.next()
+        params = self.param_list()
+        if not torch.is_grad_enabled() or not (features.requires_grad or any(p.requires_grad for p in params)):
+            with torch.no_grad():
+                return self.engine().forward_tf([p.detach() for p in params], features, caps, lengths, float(self.temperature),
+                                                bool(pretrain), noise_u, seed)
+        pred, h_n, c_n = _ForwardTfFn.apply(self.engine(), float(self.temperature), bool(pretrain), caps, lengths, noise_u, seed,
+                                            features, *params)
+        return pred, (h_n, c_n)
 
     def add_gumbel(self, o_t, eps=1e-10, gpu=0):
         """o_t + Gumbel(0,1) noise (generator.py:84-96); on the hot path this is fused into sample()."""

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GIC_ABI_VERSION 3
+#define GIC_ABI_VERSION 4
 #define GIC_MAX_LAYERS 4
 #define GIC_MAX_CONVS 8
 
@@ -190,17 +190,28 @@ void gic_debug_decoder_step(int mask);
  * (Decoder.sample, src/generator.py:55-81, takes any vocabulary / embedding size). */
 int gic_decoder_fused_rollout_rows(const gic_decoder_dims* dims, int32_t* out_rows);
 
-/* Decoder.forward, the teacher-forced decode (src/generator.py:39-53; forward only: the reference's training never calls it).
+/* Decoder.forward, the teacher-forced decode (src/generator.py:39-53; the reference's training never calls it).
  * dims->L = T = caption length + 1 time steps: step 0 is fed `features`, step t > 0 embed(caps[b, t-1]) (caps int64 [B, T-1]).
  * lengths int32 [B] (each 1..T) with pack_padded_sequence semantics: a row past its length keeps its state and contributes a
  * zero LSTM output.  Tmax = max(lengths) (the host knows it).  out: act [B, Tmax, V] = logits (pretrain != 0) or
  * softmax((logits + gumbel(u)) * temperature) with u = noise_u f32 [B, Tmax, V] (ONE draw over the whole tensor,
  * generator.py:50,86-90) or Philox(seed) when NULL.  h_n / c_n: f32 [NL, B, H], each row's state at ITS last step.
- * state: as for gic_decoder_sample_fwd with L = T; logits_ws f32 [B*Tmax, V] and ids_ws int64 [B*Tmax]: scratch. */
+ * state: as for gic_decoder_sample_fwd with L = T; logits_ws f32 [B*Tmax, V] and ids_ws int64 [B*Tmax]: scratch.  With
+ * state->gates[k] non-NULL the gate activations of every step are saved and gic_decoder_forward_tf_bwd can follow. */
 int gic_decoder_forward_tf(const gic_decoder_dims* dims, const gic_decoder_params* params, const gic_decoder_shadow* shadow,
                            const gic_decoder_state* state, const float* features, const int64_t* caps, const int32_t* lengths,
                            int Tmax, const float* noise_u, uint64_t seed, float temperature, int pretrain, float* logits_ws,
                            int64_t* ids_ws, void* out, float* h_n, float* c_n, void* stream);
+
+/* (ABI v4) autograd through Decoder.forward (src/generator.py:39-53): gradients of a loss on `out` of the gic_decoder_forward_tf
+ * call that filled `state` (same dims, caps, lengths, Tmax, temperature, pretrain; state->gates given).  pred = that call's `out`,
+ * d_pred: act [B, Tmax, V].  Padded positions (t >= lengths[b]) are pad_packed_sequence's zeros (generator.py:45): their
+ * gradient reaches b_out only.  ws / grads as for gic_decoder_sample_bwd with L = Tmax (grads->embed: scatter-add over caps;
+ * grads->features = d features).  The returned hidden (h_n, c_n) is not differentiated. */
+int gic_decoder_forward_tf_bwd(const gic_decoder_dims* dims, const gic_decoder_params* params, const gic_decoder_shadow* shadow,
+                               const gic_decoder_state* state, const gic_decoder_bwd_ws* ws, const void* pred, const int64_t* caps,
+                               const int32_t* lengths, int Tmax, const void* d_pred, float temperature, int pretrain,
+                               const gic_decoder_grads* grads, void* stream);
 
 /* d_out: act [B,L,V] gradient w.r.t. `out`; probs = the forward's `out`.
  * phases (bit mask; GIC_DECODER_BWD_ALL = both, in this order):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.library_path())
     for name in declared_symbols():
         assert hasattr(lib, name), f"libgicap.so does not export {name}"
-    assert _lib.load().gic_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.load().gic_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_argument_validation_returns_status_not_crash():
