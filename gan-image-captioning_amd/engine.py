@@ -8,6 +8,7 @@ library as a raw device pointer.  All launches go to the current PyTorch HIP str
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -532,7 +533,11 @@ class DiscEngine:
         self.V, self.De, self.R = vocab, embed_dim, num_rep
         self.fs, self.nf = list(filter_sizes), list(num_filters)
         self.F = sum(self.nf)
-        self.Fp = (self.F + 7) // 8 * 8
+        # leading dimension of the [B*R, F] activations: whole 128-byte lines per row in bf16 (64 elements), so that a 64-byte LDS-DMA piece of
+        # a row never straddles two cache lines (the highway product over cfg5's 622 592 roll-out rows: 1.65 -> 1.45 ms; cfg5 10.46 -> 10.18 ms,
+        # profiles/r03_gemm_tile16_experiment.txt)
+        pad = int(os.environ.get("GIC_DISC_FP_ALIGN", "64"))
+        self.Fp = (self.F + pad - 1) // pad * pad
         self.s = embed_dim // num_rep
         self.dt = dtype
         self.act = TORCH_DTYPE[dtype]
