@@ -491,6 +491,45 @@ __global__ void disc_highway_bwd_kernel(const float* __restrict__ dydrop, const 
   }
 }
 
+// The same, 8 consecutive columns per thread (Fp % 8 == 0, 16-byte aligned buffers): 16-byte accesses and one 32-bit division per 8
+// elements instead of 4-byte accesses and a 64-bit modulo per element (cfg2, in-step: 25 -> 19 us per launch).
+template <typename TA>
+__global__ __launch_bounds__(256) void disc_highway_bwd_vec_kernel(const float* __restrict__ dydrop, const uint8_t* __restrict__ keep, float scale,
+                                                                     const float* __restrict__ hpre, const TA* __restrict__ pooled,
+                                                                     TA* __restrict__ dh, float* __restrict__ dpooled, unsigned groups, int F, int G8) {
+  for (unsigned g = blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += gridDim.x * blockDim.x) {
+    const int n0 = (int)(g % (unsigned)G8) * 8;
+    const long i = (long)g * 8;
+    const float4 d0 = *(const float4*)(dydrop + i), d1 = *(const float4*)(dydrop + i + 4);
+    const float4 h0 = *(const float4*)(hpre + i), h1 = *(const float4*)(hpre + i + 4);
+    const float dy8[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    const float h8[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    unsigned long long kb = 0x0101010101010101ull;
+    if (keep) kb = *(const unsigned long long*)(keep + i);
+    __attribute__((aligned(16))) TA x8[8], o8[8];
+#pragma unroll
+    for (int q = 0; q < (int)(8 * sizeof(TA) / 16); ++q) ((float4*)x8)[q] = ((const float4*)(pooled + i))[q];
+    float dx8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float vdh = 0.f, vdx = 0.f;
+      if (n0 + e < F) {
+        const float dy = dy8[e] * scale * (float)((kb >> (8 * e)) & 0xffull);
+        const float h = h8[e], x = to_f32<TA>(x8[e]);
+        const float sg = 1.f / (1.f + expf(-h));
+        vdh = dy * (sg * (1.f - sg) * (fmaxf(h, 0.f) - x) + (h > 0.f ? sg : 0.f));
+        vdx = dy * (1.f - sg);
+      }
+      o8[e] = from_f32<TA>(vdh);
+      dx8[e] = vdx;
+    }
+#pragma unroll
+    for (int q = 0; q < (int)(8 * sizeof(TA) / 16); ++q) ((float4*)(dh + i))[q] = ((const float4*)o8)[q];
+    *(float4*)(dpooled + i) = make_float4(dx8[0], dx8[1], dx8[2], dx8[3]);
+    *(float4*)(dpooled + i + 4) = make_float4(dx8[4], dx8[5], dx8[6], dx8[7]);
+  }
+}
+
 struct DCtx {
   int B, L, V, De, R, s, F, Fp, dt;
   float drop_p;              // nn.Dropout p of discriminator.py:10,30
@@ -673,9 +712,16 @@ int disc_bwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
     }
   }
   // 3. highway backward
-  hipLaunchKernelGGL((disc_highway_bwd_kernel<TA>), dim3(grid1d(MR * c.Fp)), dim3(256), 0, stream, (const float*)ws->dydrop,
-                     train ? (const uint8_t*)st->keep : nullptr, c.keep_scale(train), (const float*)st->hpre,
-                     (const TA*)st->pooled, (TA*)ws->dh, ws->dpooled, MR, c.F, c.Fp);
+  const bool hb_vec = MR * c.Fp / 8 < (1l << 31) && ((((uintptr_t)ws->dydrop) | ((uintptr_t)st->hpre) | ((uintptr_t)st->pooled) | ((uintptr_t)ws->dh) |
+                                                     ((uintptr_t)ws->dpooled)) & 15) == 0 && (!train || (((uintptr_t)st->keep) & 7) == 0);
+  if (hb_vec)
+    hipLaunchKernelGGL((disc_highway_bwd_vec_kernel<TA>), dim3(grid1d(MR * c.Fp / 8)), dim3(256), 0, stream, (const float*)ws->dydrop,
+                       train ? (const uint8_t*)st->keep : nullptr, c.keep_scale(train), (const float*)st->hpre,
+                       (const TA*)st->pooled, (TA*)ws->dh, ws->dpooled, (unsigned)(MR * c.Fp / 8), c.F, c.Fp / 8);
+  else
+    hipLaunchKernelGGL((disc_highway_bwd_kernel<TA>), dim3(grid1d(MR * c.Fp)), dim3(256), 0, stream, (const float*)ws->dydrop,
+                       train ? (const uint8_t*)st->keep : nullptr, c.keep_scale(train), (const float*)st->hpre,
+                       (const TA*)st->pooled, (TA*)ws->dh, ws->dpooled, MR, c.F, c.Fp);
   GIC_CHECK_LAUNCH("disc_highway_bwd");
   {
     GemmDesc g;   // dpooled += dh hw_w
