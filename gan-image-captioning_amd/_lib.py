@@ -168,6 +168,11 @@ _SIGNATURES = {
                          C.c_int] + [C.c_int] * 9 + [c_void_p]),
     "gic_conv1x1_res_in": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_float,
                            c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),
+    "gic_conv1x1_bn_in_stats": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, C.c_float, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int64,
+                                C.c_int, C.c_int, c_void_p]),
+    "gic_conv_b2b": (C.c_int, [c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                     C.c_int, c_void_p, c_void_p, C.c_float, c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
+                     c_void_p]),
     "gic_conv2d": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int] + [C.c_int] * 9 + [c_void_p]),
     "gic_bn_act": (C.c_int, [c_void_p] * 12 + [C.c_int, C.c_float, C.c_int, c_void_p, C.c_int, C.c_int64, C.c_int, c_void_p]),
     "gic_bn_relu_maxpool": (C.c_int, [c_void_p] * 6 + [C.c_int, C.c_float, c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),

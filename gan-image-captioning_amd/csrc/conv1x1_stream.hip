@@ -29,6 +29,7 @@ struct StreamDesc {
   int M, N, lda, ldb, ldc, stats_nrep, in_nrep;
   float in_inv_count;
   int share_a;
+  int stats_only;                      // column sums only: no C stores
   int tiles_m, tiles_n, groups;        // row tiles, output-channel tiles, workgroups per output-channel tile (grid = groups * tiles_n)
   unsigned a_bytes, b_bytes;
 };
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const StreamDesc d)
       const int ml = c / CPR, cc = c % CPR;
       const int m = bm0 + ml, n = bn0 + cc * 8;
       const u32x4 v = *(const u32x4*)(buf + ml * SC + cc * 16);
-      if (m < M && n < N) *(u32x4*)(C + (long)m * d.ldc + n) = v;      // (a wave skips a store only in its last, partial row tile)
+      if (m < M && n < N && !d.stats_only) *(u32x4*)(C + (long)m * d.ldc + n) = v;      // (a wave skips a store only in its last, partial row tile)
     }
   };
   int st = 0, jj = 0, prev_bm0 = 0;
@@ -279,7 +280,7 @@ bool try_conv1x1_stream(const GemmDesc& d, hipStream_t stream) {
   if (groups > sd.tiles_m) groups = sd.tiles_m;
   sd.groups = groups;
   sd.share_a = xcd_share_a(2l * d.M * d.K, 2l * d.N * d.K, sd.tiles_n);
-  sd.A = d.A; sd.B = d.B; sd.C = d.C; sd.stats = d.stats;
+  sd.A = d.A; sd.B = d.B; sd.C = d.C; sd.stats = d.stats; sd.stats_only = d.stats_only;
   sd.in_stats = d.in_stats; sd.in_gamma = d.in_gamma; sd.in_beta = d.in_beta;
   sd.M = d.M; sd.N = d.N; sd.lda = (int)d.lda; sd.ldb = (int)d.ldb; sd.ldc = (int)d.ldc;
   sd.stats_nrep = d.stats_nrep < 1 ? 1 : d.stats_nrep; sd.in_nrep = d.in_nrep; sd.in_inv_count = d.in_inv_count;

@@ -1,0 +1,303 @@
+// conv3 -> bn3 + shortcut + ReLU -> the next block's conv1, BACK TO BACK in one launch (round 3): the tail of a torchvision bottleneck
+// and the head of the next one (reference src/generator.py:12-14) on the large maps, where both are HBM-bound.
+//
+//   y3   = conv3(relu(bn2(y2)))                     1x1, C2 -> C3 = 4 C2   (y2 = the raw output of conv2, normalised on load)
+//   out  = relu(bn3(y3) + shortcut)                 the block output (written: the next block's shortcut)
+//   y1n  = conv1_next(out)                          1x1, C3 -> C1N          (+ its BatchNorm column sums)
+//
+// As separate launches (conv1x1_stream for conv3, tile8's residual-on-load form for conv1_next) y3 is written and read again:
+// 2 x 103 MB per block at 56 x 56 and batch 64, the largest tensor of the block, between two kernels that already run at 4-6 TB/s.
+// Here y3 never reaches memory.  BatchNorm needs y3's batch statistics BEFORE any of it can be normalised, so conv3 runs twice:
+// a statistics-only pass first (the streaming kernel without its stores: reads y2, 26 MB) and the recomputation in this kernel.
+//
+// The intermediate stays in REGISTERS.  A wave owns 16 pixels.  Per 64-channel chunk of C3 it computes conv3 in the transposed form
+// (MFMA A operand = W3 rows, B operand = its pixels): a lane then holds ONE pixel and, with the chunk's W3 rows laid out in LDS in
+// the order row x of block j <-> channel 16 (x >> 2) + 4 j + (x & 3), 16 CONSECUTIVE channels of it -- 32 contiguous bytes of the
+// shortcut to load, of the block output to store, and, rounded to bf16, exactly two B-operand fragments of the second product
+// (k slot (lg, e) <-> channel 16 lg + 8 ks + e; the W1n chunk is read with the same k order: one 16-byte LDS read per fragment).
+// No LDS round trip and no workgroup barrier between the two products; conv1_next's output comes out transposed the same way
+// (16 consecutive output channels of a pixel per lane: 32-byte stores), its column sums stay per lane in registers across all tiles.
+// Only the weight chunks are shared: a two-stage LDS-DMA ring (W3 chunk + W1n chunk, both L2-resident), one barrier per chunk; the
+// workgroup is persistent and small (weights ring + coefficient tables), so two or three share a CU and cover each other's latency.
+#include <stdlib.h>
+
+#include "conv_b2b.h"
+#include "bn_fold.h"
+
+namespace gic {
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Sum over the 16 lanes of a row (lr) of 16 per-lane values, value e ending up in lane lr == e: a reduce-scatter butterfly, 15 lane
+// exchanges and 15 additions instead of 16 separate registers that live across the whole kernel.
+__device__ __forceinline__ float row_reduce_scatter16(const float (&v)[16], const int lr) {
+  float t[8], u[4], x[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const bool up = lr & 8; t[i] = (up ? v[i + 8] : v[i]) + __shfl_xor(up ? v[i] : v[i + 8], 8, 64); }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const bool up = lr & 4; u[i] = (up ? t[i + 4] : t[i]) + __shfl_xor(up ? t[i] : t[i + 4], 4, 64); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const bool up = lr & 2; x[i] = (up ? u[i + 2] : u[i]) + __shfl_xor(up ? u[i] : u[i + 2], 2, 64); }
+  const bool up = lr & 1;
+  return (up ? x[1] : x[0]) + __shfl_xor(up ? x[0] : x[1], 1, 64);
+}
+
+// C2: channels of y2 (64 | 128); C1N: output channels of the next conv1 (64 | 128); IDENT: identity shortcut (no BatchNorm of its own)
+template <int C2, int C1N, bool IDENT>
+__global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
+  constexpr int NT = 256, NW = NT / 64, BM = 16 * NW, C3 = 4 * C2, NC = C3 / 64, KS1 = C2 / 32, G2 = C1N / 64;
+  constexpr int W3_BYTES = 64 * C2 * 2, W1_BYTES = C1N * 128, STAGE = W3_BYTES + W1_BYTES;
+  constexpr int PW3 = W3_BYTES / 16 / NT, PW1 = W1_BYTES / 16 / NT;       // DMA pieces per thread and chunk
+  constexpr int COEF0 = 2 * STAGE;
+  constexpr int ROW3 = C2 * 2, CH3 = ROW3 / 16;                           // bytes / 16-byte pieces of a W3 row (128 | 256 B)
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(PW3 >= 1 && PW1 >= 1, "piece counts");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* coef2 = (float*)(smem + COEF0);                                 // [C2][2]  bn2 scale, shift
+  float* coef3 = coef2 + 2 * C2;                                         // [C3][2]  bn3
+  float* coefr = coef3 + 2 * C3;                                         // [C3][2]  shortcut (identity: 1, 0)
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int ntiles = (d.M + BM - 1) / BM;
+
+  const __amdgpu_buffer_rsrc_t rsW3 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w3, 0, C3 * C2 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w1n, 0, C1N * C3 * 2, 0x00020000);
+  const int wbase = (tid & ~63) * 16;
+
+  // ---- weight chunk c -> ring stage st_.  LDS images: W3 chunk [64 rows][C2] with LDS row L = 16 j + x holding channel
+  //      16 (x >> 2) + 4 j + (x & 3) of the chunk; W1n chunk [C1N rows][64] with LDS row 64 g + 16 jb + x holding output channel
+  //      64 g + 16 (x >> 2) + 4 jb + (x & 3); 16-byte pieces XOR-swizzled by (row >> 1) & 7 within each 128 bytes of a row.
+  auto issue_w = [&](const int c, const int st_) {
+    unsigned char* s0 = smem + st_ * STAGE;
+    const bool ok = c < NC;
+#pragma unroll
+    for (int i = 0; i < PW3; ++i) {
+      const int q = tid + NT * i, L = q / CH3, slot = q % CH3;
+      const int j = L >> 4, x = L & 15, ch = 16 * (x >> 2) + 4 * j + (x & 3);
+      const int kp = (slot & ~7) | ((slot & 7) ^ ((L >> 1) & 7));         // logical 16-byte piece of the row
+      const unsigned voff = ok ? (unsigned)((c * 64 + ch) * C2 + kp * 8) * 2u : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW3, (lds_void_ptr)(s0 + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PW1; ++i) {
+      const int q = tid + NT * i, L = q >> 3, slot = q & 7;
+      const int g = L >> 6, jb = (L >> 4) & 3, x = L & 15, qo = 64 * g + 16 * (x >> 2) + 4 * jb + (x & 3);
+      const int kp = slot ^ ((L >> 1) & 7);
+      const unsigned voff = ok ? (unsigned)(qo * C3 + c * 64 + kp * 8) * 2u : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (lds_void_ptr)(s0 + W3_BYTES + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, 0);
+    }
+  };
+
+  issue_w(0, 0);
+  // ---- coefficient tables
+  for (int c = tid; c < C2 + 2 * C3; c += NT) {
+    float sc, sh;
+    if (c < C2 + C3) {
+      const bool two = c < C2;
+      const int cc = two ? c : c - C2, Cn = two ? C2 : C3;
+      float s1, s2;
+      fold_replicas(two ? d.stats2 : d.stats3, two ? d.nrep2 : d.nrep3, Cn, cc, s1, s2);
+      const float mean = s1 * d.inv_count, var = fmaxf(s2 * d.inv_count - mean * mean, 0.f);
+      sc = (two ? d.gamma2 : d.gamma3)[cc] * rsqrtf(var + 1e-5f);        // kBnEps of encoder.hip (nn.BatchNorm2d default)
+      sh = (two ? d.beta2 : d.beta3)[cc] - mean * sc;
+    } else {
+      const int cc = c - C2 - C3;
+      sc = 1.f; sh = 0.f;                                                // identity shortcut
+      if (d.res_stats) {                                                 // projection shortcut: its own BatchNorm
+        float s1, s2;
+        fold_replicas(d.res_stats, d.res_nrep, C3, cc, s1, s2);
+        const float mean = s1 * d.inv_count, var = fmaxf(s2 * d.inv_count - mean * mean, 0.f);
+        sc = d.res_gamma[cc] * rsqrtf(var + 1e-5f);
+        sh = d.res_beta[cc] - mean * sc;
+      }
+    }
+    coef2[2 * c] = sc; coef2[2 * c + 1] = sh;                            // (the three tables are contiguous)
+  }
+
+  const bf16_t* __restrict__ y2 = (const bf16_t*)d.y2;
+  const bf16_t* __restrict__ res = (const bf16_t*)d.res;
+  bf16_t* __restrict__ out = (bf16_t*)d.out;
+  bf16_t* __restrict__ y1n = (bf16_t*)d.y1n;
+
+  float st_s[G2], st_q[G2];                                              // conv1_next's column sums over this wave's pixels, all tiles: lane (lr, lg) holds column 64 g + 16 lg + lr
+#pragma unroll
+  for (int g = 0; g < G2; ++g) st_s[g] = st_q[g] = 0.f;
+
+  int st = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long m = (long)tile * BM + w * 16 + lr;                        // this lane's pixel
+    const bool mok = m < d.M;
+    const long mc = mok ? m : d.M - 1;                                   // rows past M repeat the last pixel (never stored, never summed)
+    // y2 fragments of the pixel (B operand of conv3: k slots lg * 8 .. + 7 of each 32-deep slice), bn2 + ReLU in registers
+    bf16x8 fy[KS1];
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) fy[ks] = *(const bf16x8*)(y2 + mc * C2 + ks * 32 + lg * 8);
+    f32x4 acc2[G2][4];
+#pragma unroll
+    for (int g = 0; g < G2; ++g)
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) acc2[g][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // the shortcut's 16 channels of this pixel in chunk 0 (later chunks: requested at the end of the previous one)
+    u32x4 r0 = *(const u32x4*)(res + mc * C3 + lg * 16), r1 = *(const u32x4*)(res + mc * C3 + lg * 16 + 8);
+#pragma unroll 1
+    for (int c = 0; c < NC; ++c) {
+      // This thread's weight pieces of chunk c have landed once only what was issued BEHIND them is outstanding (one in-order counter for
+      // loads, LDS-DMA and stores): the previous chunk's two block-output stores and this chunk's two shortcut loads -- at a tile's first
+      // chunk also the previous tile's y1n stores and this tile's y2 loads.  Nothing waits for a store to complete.
+      if (c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 2 * G2 + KS1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __syncthreads();                                                   // chunk c's stage (and, the first time, the tables) visible; stage st ^ 1 is free
+      issue_w(c + 1 < NC ? c + 1 : (tile + (int)gridDim.x < ntiles ? 0 : NC), st ^ 1);   // the next chunk (of the next tile; none after the last)
+      if (c == 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+          const float4* cp = (const float4*)(coef2 + 2 * (ks * 32 + lg * 8));
+          const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+          const float scl[8] = {c0.x, c0.z, c1.x, c1.z, c2.x, c2.z, c3.x, c3.z};
+          const float sft[8] = {c0.y, c0.w, c1.y, c1.w, c2.y, c2.w, c3.y, c3.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fy[ks][e] = (bf16_t)fmaxf((float)fy[ks][e] * scl[e] + sft[e], 0.f);
+        }
+      }
+      const unsigned char* sW3 = smem + st * STAGE;
+      const unsigned char* sW1 = sW3 + W3_BYTES;
+      // ---- conv3, transposed: block j, MFMA row x <-> channel 16 (x >> 2) + 4 j + (x & 3): lane (lr, lg) ends up with channels 16 lg + 4 j + r
+      f32x4 acc1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int L = 16 * j + lr, kp = ks * 4 + lg;
+          const bf16x8 fw = *(const bf16x8*)(sW3 + L * ROW3 + (((kp & ~7) | ((kp & 7) ^ ((L >> 1) & 7))) << 4));
+          acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fy[ks], acc1[j], 0, 0, 0);
+        }
+      }
+      // ---- bn3 + shortcut + ReLU: 16 consecutive channels 64 c + 16 lg + e, e = 4 j + r
+      const bf16_t* rv0 = (const bf16_t*)&r0;
+      const bf16_t* rv1 = (const bf16_t*)&r1;
+      bf16x8 a2[2];                                                      // the block output's 16 channels = two B-operand fragments of conv1_next
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const float4 p3 = *(const float4*)(coef3 + 2 * (c * 64 + lg * 16 + e));     // (sc, sh) of channels e, e + 1
+        float x0 = (float)(e < 8 ? rv0[e] : rv1[e - 8]), x1 = (float)(e + 1 < 8 ? rv0[e + 1] : rv1[e + 1 - 8]);
+        if constexpr (!IDENT) {
+          const float4 pr = *(const float4*)(coefr + 2 * (c * 64 + lg * 16 + e));
+          x0 = x0 * pr.x + pr.y; x1 = x1 * pr.z + pr.w;
+        }
+        const float v0 = fmaxf(acc1[e >> 2][e & 3] * p3.x + p3.y + x0, 0.f);
+        const float v1 = fmaxf(acc1[(e + 1) >> 2][(e + 1) & 3] * p3.z + p3.w + x1, 0.f);
+        a2[e >> 3][e & 7] = (bf16_t)v0;
+        a2[(e + 1) >> 3][(e + 1) & 7] = (bf16_t)v1;
+      }
+      // (rows past M store to the last pixel's address as well: the same values, and the count of outstanding operations stays uniform)
+      if (!(d.dbg & 1)) {
+      *(bf16x8*)(out + mc * C3 + c * 64 + lg * 16) = a2[0];
+      *(bf16x8*)(out + mc * C3 + c * 64 + lg * 16 + 8) = a2[1];
+      }
+      if (c + 1 < NC && !(d.dbg & 2)) {
+        r0 = *(const u32x4*)(res + mc * C3 + (c + 1) * 64 + lg * 16);
+        r1 = *(const u32x4*)(res + mc * C3 + (c + 1) * 64 + lg * 16 + 8);
+      }
+      // ---- conv1_next, transposed: acc2[g][jb] += W1n rows (A operand) x a2 (B operand, k slot (lg, e) <-> chunk channel 16 lg + 8 ks + e)
+      if (!(d.dbg & 4))
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int g = 0; g < G2; ++g)
+#pragma unroll
+          for (int jb = 0; jb < 4; ++jb) {
+            const int L = 64 * g + 16 * jb + lr, kp = lg * 2 + ks;       // 16-byte piece of the row: channels 16 lg + 8 ks .. + 7
+            const bf16x8 fw = *(const bf16x8*)(sW1 + L * 128 + ((kp ^ ((L >> 1) & 7)) << 4));
+            acc2[g][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, a2[ks], acc2[g][jb], 0, 0, 0);
+          }
+      }
+      st ^= 1;
+    }
+    if (d.dbg & 1) continue;
+    // ---- y1n: lane (lr, lg) holds output channels 64 g + 16 lg + 4 jb + r of its pixel: 32 contiguous bytes per g
+#pragma unroll
+    for (int g = 0; g < G2; ++g) {
+      bf16x8 o[2];
+      float vs[16], vq[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = acc2[g][e >> 2][e & 3];
+        o[e >> 3][e & 7] = (bf16_t)v;
+        vs[e] = mok ? v : 0.f;
+        vq[e] = vs[e] * vs[e];
+      }
+      st_s[g] += row_reduce_scatter16(vs, lr);
+      st_q[g] += row_reduce_scatter16(vq, lr);
+      *(bf16x8*)(y1n + mc * C1N + g * 64 + lg * 16) = o[0];
+      *(bf16x8*)(y1n + mc * C1N + g * 64 + lg * 16 + 8) = o[1];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // a trailing zero-fill DMA must land before the LDS is handed on
+
+  // ---- conv1_next's BatchNorm column sums: fold the 16 pixels of the wave (lanes lr), then the eight waves through LDS (the weight ring is
+  //      idle now): ONE atomic per column and workgroup (one per wave measured 250-460 us per launch: half a million atomics on a few
+  //      hundred addresses)
+  __syncthreads();
+  float* red = (float*)smem;                                             // [NW waves][2][C1N]
+#pragma unroll
+  for (int g = 0; g < G2; ++g) {
+    const int col = g * 64 + lg * 16 + lr;
+    red[(w * 2) * C1N + col] = st_s[g];
+    red[(w * 2 + 1) * C1N + col] = st_q[g];
+  }
+  __syncthreads();
+  for (int t_ = tid; t_ < 2 * C1N; t_ += NT) {
+    const int tid = t_;
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) v += red[ww * 2 * C1N + tid];
+    atomicAdd(d.stats1 + (long)(blockIdx.x % d.nrep1) * 2 * C1N + tid, v);
+  }
+}
+
+template <int C2, int C1N, bool IDENT>
+bool launch_b2b(const B2bDesc& d, hipStream_t stream) {
+  constexpr int C3 = 4 * C2;
+  constexpr size_t lds = 2 * (64 * C2 * 2 + C1N * 128) + (size_t)(C2 + 2 * C3) * 8;
+  static_assert(lds <= 160 * 1024, "conv_b2b LDS budget");
+  static LdsGrant granted;
+  if (!grant_lds(conv_b2b_kernel<C2, C1N, IDENT>, lds, granted)) return false;
+  static const int per_cu = [] { const char* e = getenv("GIC_B2B_WG_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 2; }();
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 256; }
+    return n;
+  }();
+  const int tiles = cdiv(d.M, 64);
+  const int grid = tiles < cus * per_cu ? tiles : cus * per_cu;
+  hipLaunchKernelGGL((conv_b2b_kernel<C2, C1N, IDENT>), dim3((unsigned)grid), dim3(256), lds, stream, d);
+  return true;
+}
+
+}  // namespace
+
+bool try_conv_b2b(const B2bDesc& d, int C2, int C1N, hipStream_t stream) {
+  static const bool off = getenv("GIC_NO_CONV_B2B") != nullptr;
+  if (off || d.M <= 0 || d.nrep1 < 1) return false;
+  static const int dbg = [] { const char* e = getenv("GIC_B2B_DBG"); return e ? atoi(e) : 0; }();
+  B2bDesc dd = d; dd.dbg = dbg;
+  const long C3 = 4l * C2;
+  if ((long)d.M * C3 * 2 >= (1l << 40)) return false;
+  for (const void* p : {d.y2, d.w3, d.res, d.w1n, (const void*)d.out, (const void*)d.y1n})
+    if (!p || (((uintptr_t)p) & 15)) return false;
+  const bool ident = d.res_stats == nullptr;
+  static const int only = [] { const char* e = getenv("GIC_B2B_ONLY"); return e ? atoi(e) : 0; }();      // tuning: 1 = C2 == 128 only, 2 = all but (64, 128)
+  if ((only == 1 && C2 != 128) || (only == 2 && C2 == 64 && C1N == 128)) return false;
+  if (C2 == 64 && C1N == 64) return ident ? launch_b2b<64, 64, true>(dd, stream) : launch_b2b<64, 64, false>(dd, stream);
+  if (C2 == 64 && C1N == 128) return ident ? launch_b2b<64, 128, true>(dd, stream) : launch_b2b<64, 128, false>(dd, stream);
+  if (C2 == 128 && C1N == 128) return ident ? launch_b2b<128, 128, true>(dd, stream) : launch_b2b<128, 128, false>(dd, stream);
+  return false;
+}
+
+}  // namespace gic

@@ -15,6 +15,7 @@
 #include "../../include/gicap.h"
 #include "kernels.h"
 #include "bn_fold.h"
+#include "conv_b2b.h"
 
 namespace gic {
 namespace {
@@ -416,6 +417,46 @@ int gic_conv2d_bn_in(const void* in, const float* in_stats, int in_nrep, const f
   g.stats_nrep = stats_nrep < 1 ? 1 : stats_nrep;
   g.in_stats = in_stats; g.in_nrep = in_nrep; g.in_gamma = in_gamma; g.in_beta = in_beta; g.in_inv_count = 1.f / in_count;
   return gemm(g, (hipStream_t)stream);
+}
+
+int gic_conv1x1_bn_in_stats(const void* in, const float* in_stats, int in_nrep, const float* in_gamma, const float* in_beta, float in_count,
+                            const void* w, float* stats, int stats_nrep, int dtype, int64_t rows, int Cin, int Cout, void* stream) {
+  GIC_CHECK_ARG(in && in_stats && in_gamma && in_beta && w && stats && in_count > 0 && in_nrep >= 1 && rows > 0 && Cin > 0 && Cout > 0,
+                "conv1x1_bn_in_stats: bad argument");
+  if (dtype != DT_BF16 || rows >= (1l << 31)) return GIC_ERR_UNSUPPORTED;
+  GemmDesc g;
+  g.A = in; g.B = w; g.C = (void*)in;                       // never written (stats_only): any non-null pointer
+  g.M = (int)rows; g.N = Cout; g.K = Cin;
+  g.lda = Cin; g.ldb = g.K; g.ldc = Cout;
+  g.in_dtype = dtype; g.out_dtype = dtype;
+  g.conv = 1; g.cH = 1; g.cW = (int)rows; g.cCin = Cin; g.cHo = 1; g.cWo = (int)rows; g.cKH = 1; g.cKW = 1; g.cStride = 1; g.cPad = 0;
+  g.epi = EPI_BNSTATS;
+  g.stats = stats;
+  g.stats_nrep = stats_nrep < 1 ? 1 : stats_nrep;
+  g.in_stats = in_stats; g.in_nrep = in_nrep; g.in_gamma = in_gamma; g.in_beta = in_beta; g.in_inv_count = 1.f / in_count;
+  g.stats_only = 1;
+  return gemm(g, (hipStream_t)stream);
+}
+
+int gic_conv_b2b(const void* y2, const float* stats2, int nrep2, const float* gamma2, const float* beta2, const void* w3, const float* stats3,
+                 int nrep3, const float* gamma3, const float* beta3, const void* res, const float* res_stats, int res_nrep,
+                 const float* res_gamma, const float* res_beta, float count, void* block_out, const void* w1n, void* y1n, float* stats1,
+                 int nrep1, int dtype, int64_t rows, int C2, int C1N, void* stream) {
+  GIC_CHECK_ARG(y2 && stats2 && gamma2 && beta2 && w3 && stats3 && gamma3 && beta3 && res && block_out && w1n && y1n && stats1 && count > 0 &&
+                    nrep2 >= 1 && nrep3 >= 1 && rows > 0, "conv_b2b: bad argument");
+  GIC_CHECK_ARG(!res_stats || (res_gamma && res_beta && res_nrep >= 1), "conv_b2b: the shortcut's BatchNorm needs gamma and beta");
+  if (dtype != DT_BF16 || rows >= (1l << 31)) return GIC_ERR_UNSUPPORTED;
+  B2bDesc d;
+  d.y2 = y2; d.w3 = w3; d.res = res; d.w1n = w1n; d.out = block_out; d.y1n = y1n;
+  d.stats2 = stats2; d.gamma2 = gamma2; d.beta2 = beta2; d.stats3 = stats3; d.gamma3 = gamma3; d.beta3 = beta3;
+  d.res_stats = res_stats; d.res_gamma = res_gamma; d.res_beta = res_beta; d.stats1 = stats1;
+  d.nrep2 = nrep2; d.nrep3 = nrep3; d.res_nrep = res_nrep; d.nrep1 = nrep1 < 1 ? 1 : nrep1;
+  d.inv_count = 1.f / count; d.M = (int)rows;
+  if (rows * C2 * 2 >= (1l << 31) || rows * 4 * C2 * 2 >= (1l << 31)) return GIC_ERR_UNSUPPORTED;
+  d.y2_bytes = (unsigned)(rows * C2 * 2); d.res_bytes = (unsigned)(rows * 4 * C2 * 2);
+  if (!try_conv_b2b(d, C2, C1N, (hipStream_t)stream)) return GIC_ERR_UNSUPPORTED;
+  GIC_CHECK_LAUNCH("conv_b2b");
+  return GIC_OK;
 }
 
 int gic_conv1x1_res_in(const void* in, const float* in_stats, int in_nrep, const float* in_gamma, const float* in_beta, const void* res,

@@ -71,6 +71,8 @@ struct GemmDesc {
   const float* gm_u = nullptr; long gm_ldu = 0;
   float gm_temperature = 1.f;
   int n_fast = 0;           // tile8: the output-channel tiles of a row tile are neighbours on one XCD (xcd_share_a) instead of the row tiles of a channel tile
+  int stats_only = 0;       // EPI_BNSTATS convolutions the streaming 1x1 kernel takes: the column sums only, C is NOT written (conv_b2b.hip's first pass);
+                            // honoured by conv1x1_stream.hip alone: gemm() answers GIC_ERR_UNSUPPORTED when that kernel declines the shape
   int dbg = 0;              // phase-ablation knob, honoured only by -DGIC_STAMPS tool builds
 };
 

@@ -1249,6 +1249,7 @@ int pick_conv(const GemmDesc& d, hipStream_t stream) {
     if (try_conv3x3_patch(d, stream)) { GIC_CHECK_LAUNCH("conv3x3 patch"); return GIC_OK; }
     // shallow 1x1 layers over many rows: persistent workgroups, resident weights, A tiles streamed across row tiles (conv1x1_stream.hip)
     if (try_conv1x1_stream(d, stream)) { GIC_CHECK_LAUNCH("conv1x1 stream"); return GIC_OK; }
+    if (d.stats_only) return GIC_ERR_UNSUPPORTED;               // (no message: callers probe)
     // K = 256 into many output channels: the A panel of a row tile loaded / normalised once for all its channel tiles (conv1x1_panel.hip)
     if (try_conv1x1_panel(d, stream)) { GIC_CHECK_LAUNCH("conv1x1 panel"); return GIC_OK; }
     if (d.in_stats && d.cKH * d.cKW > 1) return GIC_ERR_UNSUPPORTED;

@@ -99,6 +99,11 @@ class TrunkPlan:
         self.fuse_res = os.environ.get("GIC_FUSED_RES_IN", "1") != "0"
         self.res_min_rows = int(os.environ.get("GIC_RES_IN_MIN_ROWS", "50000"))
         self.res_max_cout = int(os.environ.get("GIC_RES_IN_MAX_COUT", "128"))
+        # ... and, where the kernels exist, WITHOUT conv3's output ever reaching memory: conv3 runs as a statistics-only pass and is
+        # recomputed inside the launch that forms the block output and runs the next conv1 (gic_conv_b2b; GIC_NO_CONV_B2B=1: off)
+        self.fuse_b2b = not os.environ.get("GIC_NO_CONV_B2B")
+        self.b2b_only = int(os.environ.get("GIC_B2B_ONLY", "2"))     # 0 = every boundary the kernels take, 1 = the 28 x 28 blocks only, 2 = all but
+        # the 56 x 56 boundary into 128 output channels (measured slower there: 83 us against 56 + 6)
         self._nrep = {}
         self.use_graph = not os.environ.get("GIC_NO_GRAPH")
         self.pending_tracked = 0
@@ -265,6 +270,53 @@ class TrunkPlan:
         c1.fused_in = True
         return True
 
+    def unstored_convs(self) -> set:
+        """Names of the convolutions whose raw output the last training pass never stored (conv3 recomputed inside gic_conv_b2b): what a
+        storage-emulating reference has to leave unrounded."""
+        return {blk["c3"].name for blk in self.blocks if blk.get("b2b") is True}
+
+    def _b2b_ok(self, blk: dict, nxt: Optional[dict], rows_: int, training: bool) -> bool:
+        """conv3 of `blk` + the block output + conv1 of `nxt` as gic_conv1x1_bn_in_stats + gic_conv_b2b (shapes the kernels exist for)."""
+        if not (training and self.fuse_res and self.fuse_b2b and self.fuse_in and self.dtype != L.F32) or nxt is None or blk.get("b2b") is False:
+            return False
+        if blk["kind"] != "bottleneck" or nxt["kind"] != "bottleneck":
+            return False
+        c2, c3, c1n = blk["c2"], blk["c3"], nxt["c1"]
+        if (self.b2b_only == 1 and c2.cout != 128) or (self.b2b_only == 2 and (c2.cout, c1n.cout) == (64, 128)):
+            return False
+        return (c3.k == 1 and c3.stride == 1 and c1n.k == 1 and c1n.stride == 1 and c3.cout == 4 * c2.cout and c1n.cin == c3.cout and
+                (c2.cout, c1n.cout) in ((64, 64), (64, 128), (128, 128)) and rows_ % 64 == 0 and rows_ >= self.res_min_rows)
+
+    def _conv3_stats_only(self, blk: dict, y2, stats, rows_c2: int, rows_: int) -> bool:
+        c2, c3 = blk["c2"], blk["c3"]
+        base = stats.data_ptr()
+        with self._traced(c3.name):
+            status = L.load().gic_conv1x1_bn_in_stats(ptr(y2), base + 4 * c2.stats_off, self._nrep[c2.name], ptr(c2.bn.weight.detach()),
+                                                      ptr(c2.bn.bias.detach()), float(rows_c2), ptr(c3.w), base + 4 * c3.stats_off,
+                                                      self._nrep[c3.name], self.dtype, rows_, c2.cout, c3.cout, stream_ptr())
+        if status == L.ERR_UNSUPPORTED:
+            if self.conv_trace:
+                self.conv_trace.pop()
+            blk["b2b"] = False
+            return False
+        _check(status, "gic_conv1x1_bn_in_stats " + c3.name)
+        blk["b2b"] = True
+        return True
+
+    def _conv_b2b(self, pb, c1: _ConvStep, y1, stats) -> None:
+        """pb = (c2, y2, c3, shortcut tensor, shortcut step | None, rows, out buffer): the pending block's tail + this block's conv1."""
+        c2, y2, c3, res, res_step, rows_, out = pb
+        base = stats.data_ptr()
+        with self._traced(c1.name):
+            status = L.load().gic_conv_b2b(
+                ptr(y2), base + 4 * c2.stats_off, self._nrep[c2.name], ptr(c2.bn.weight.detach()), ptr(c2.bn.bias.detach()), ptr(c3.w),
+                base + 4 * c3.stats_off, self._nrep[c3.name], ptr(c3.bn.weight.detach()), ptr(c3.bn.bias.detach()), ptr(res),
+                base + 4 * res_step.stats_off if res_step is not None else None, self._nrep[res_step.name] if res_step is not None else 1,
+                ptr(res_step.bn.weight.detach()) if res_step is not None else None, ptr(res_step.bn.bias.detach()) if res_step is not None else None,
+                float(rows_), ptr(out), ptr(c1.w), ptr(y1), base + 4 * c1.stats_off, self._nrep[c1.name], self.dtype, rows_, c2.cout, c1.cout,
+                stream_ptr())
+        _check(status, "gic_conv_b2b " + c1.name)      # (eligibility was decided by _b2b_ok: a refusal here would leave the block output unformed)
+
     def _bn_args(self, s: Optional[_ConvStep], stats: Optional[torch.Tensor], training: bool):
         """(stats, gamma, beta, run_mean, run_var) pointers of one BatchNorm; all None for 'no BN'."""
         if s is None:
@@ -357,9 +409,12 @@ class TrunkPlan:
                 self._bn_act(last, ylast, out, stats, training, rows_, res=res, res_step=res_step)
                 pend = None
 
-        for blk, e in zip(self.blocks, b["blocks"]):
+        pend_b2b = None  # ... or one whose conv3 ran as a statistics-only pass: (c2, y2, c3, shortcut, shortcut step | None, rows, out buffer)
+        for bi, (blk, e) in enumerate(zip(self.blocks, b["blocks"])):
             c1, c2, c3, ds = blk["c1"], blk["c2"], blk["c3"], blk["ds"]
             hin, ho = e["hin"], e["hout"]
+            nxt = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
+            b2b = False
             if blk["kind"] == "basic":
                 flush()
                 self._conv(c1, x, e["y1"], stats, N, hin, hin)
@@ -368,21 +423,28 @@ class TrunkPlan:
             else:
                 # conv1: if the previous block's output is pending, it is formed on load (bn3 + shortcut + relu) and written by the
                 # convolution's first N tile; otherwise a plain convolution on the materialised input
-                if pend is None or not self._conv1_res_in(pend, c1, e["y1"], stats, N, hin, hin):
+                if pend_b2b is not None:
+                    self._conv_b2b(pend_b2b, c1, e["y1"], stats)
+                    pend_b2b = None
+                elif pend is None or not self._conv1_res_in(pend, c1, e["y1"], stats, N, hin, hin):
                     flush()
                     self._conv(c1, x, e["y1"], stats, N, hin, hin)
                 pend = None
                 # bn1 + ReLU ride into the 3x3 convolution where its input patch stays in LDS (stride 1: normalised once per chunk,
                 # not once per tap; the library declines the stride-2 ones: bn_act + plain convolution), bn2 + ReLU into conv3
                 self._bn_relu_conv(c1, e["y1"], e["z1"], c2, e["y2"], stats, training, N, hin, hin, rows[c1.name])
-                self._bn_relu_conv(c2, e["y2"], e["z2"], c3, e["y3"], stats, training, N, ho, ho, rows[c2.name])
+                b2b = self._b2b_ok(blk, nxt, rows[c3.name], training) and self._conv3_stats_only(blk, e["y2"], stats, rows[c2.name], rows[c3.name])
+                if not b2b:
+                    self._bn_relu_conv(c2, e["y2"], e["z2"], c3, e["y3"], stats, training, N, ho, ho, rows[c2.name])
                 last, ylast = c3, e["y3"]
             if ds is not None:
                 self._conv(ds, x, e["yd"], stats, N, hin, hin)        # reads the (by now materialised) block input
                 res, res_step = e["yd"], ds
             else:
                 res, res_step = x, None
-            if fuse_res and blk["kind"] != "basic":
+            if blk["kind"] != "basic" and b2b:
+                pend_b2b = (c2, e["y2"], c3, res, res_step, rows[c3.name], e["out"])
+            elif fuse_res and blk["kind"] != "basic":
                 pend = (last, ylast, res, res_step, rows[last.name], e["out"])
             else:
                 self._bn_act(last, ylast, e["out"], stats, training, rows[last.name], res=res, res_step=res_step)
@@ -398,7 +460,12 @@ class TrunkPlan:
         """One launch of the step's convolution for layer `s` as the training forward issues it (measurement helper): the
         A-side-BatchNorm variant where the plan uses it (prev = (producer step, its raw output, its row count)), the residual-on-load
         variant (prev = ("res", pending tuple)), else gic_conv2d."""
-        if prev is not None and prev[0] == "res":
+        if prev is not None and prev[0] == "b2b":
+            self._conv_b2b(prev[1], s, yo, stats)
+        elif prev is not None and prev[0] == "b2bstats":
+            if not self._conv3_stats_only(prev[1], prev[2], stats, prev[3], prev[4]):
+                raise RuntimeError("statistics-only conv3 refused for " + s.name)
+        elif prev is not None and prev[0] == "res":
             if s.fused_in and self._conv1_res_in(prev[1], s, yo, stats, N, H, W):
                 return
             self._conv(s, xi, yo, stats, N, H, W, **kw)
@@ -416,20 +483,28 @@ class TrunkPlan:
         out = [(self.stem, b["xin"], b["y0"], S + 6, S + 6, dict(cin=4, kw=8, pad=0), b["y0"].shape[1] ** 2 * N * 64 * 147, None)]
         x = b["x0"]
         pend = None
+        pend_b2b = None
         for blk, e in zip(self.blocks, b["blocks"]):
             c1, c2, c3, ds = blk["c1"], blk["c2"], blk["c3"], blk["ds"]
             hin, ho = e["hin"], e["hout"]
-            seq = [(c1, x, e["y1"], hin, ("res", pend) if (pend is not None and c1.fused_in) else None),
+            first = ("b2b", pend_b2b) if pend_b2b is not None else (("res", pend) if (pend is not None and c1.fused_in) else None)
+            seq = [(c1, x, e["y1"], hin, first),
                    (c2, e["z1"], e["y2"], ho if blk["kind"] == "basic" else hin, (c1, e["y1"], b["rows"][c1.name]))]
+            b2b = c3 is not None and blk.get("b2b") is True                 # (as the last training pass decided it)
             if c3 is not None:
-                seq.append((c3, e["z2"], e["y3"], ho, (c2, e["y2"], b["rows"][c2.name])))
+                seq.append((c3, e["z2"], e["y3"], ho, ("b2bstats", blk, e["y2"], b["rows"][c2.name], b["rows"][c3.name]) if b2b
+                            else (c2, e["y2"], b["rows"][c2.name])))
             if ds is not None:
                 seq.append((ds, x, e["yd"], hin, None))
             for s, xi, yo, hh, prev in seq:
                 out.append((s, xi, yo, hh, hh, {}, yo.shape[0] * yo.shape[1] * yo.shape[2] * s.cout * s.cin * s.k * s.k, prev))
+            pend = pend_b2b = None
             if blk["kind"] != "basic":
                 last = c3
-                pend = (last, e["y3"], e["yd"] if ds is not None else x, ds, b["rows"][last.name], e["out"])
+                if b2b:
+                    pend_b2b = (c2, e["y2"], c3, e["yd"] if ds is not None else x, ds, b["rows"][c3.name], e["out"])
+                else:
+                    pend = (last, e["y3"], e["yd"] if ds is not None else x, ds, b["rows"][last.name], e["out"])
             x = e["out"]
         return out
 

@@ -444,6 +444,24 @@ int gic_conv1x1_res_in(const void* in, const float* in_stats, int in_nrep, const
                        const float* res_stats, int res_nrep, const float* res_gamma, const float* res_beta, float count, void* block_out,
                        const void* w, void* out, float* stats, int stats_nrep, int dtype, int N, int H, int W, int Cin, int Cout,
                        void* stream);
+
+/* (ABI v4) The tail of a bottleneck block and the head of the next one in ONE launch, with conv3's output never written
+ * (src/generator.py:12-14: `out = relu(bn3(conv3(relu(bn2(y2)))) + shortcut)` followed by the next block's conv1):
+ *   gic_conv1x1_bn_in_stats   conv3's BatchNorm column sums ONLY (its own statistics have to exist before any of its output can be
+ *                             normalised): in = y2 act [rows, Cin] read as relu(bn(in)) as in gic_conv2d_bn_in, w act [Cout, Cin],
+ *                             stats [stats_nrep][2*Cout] added to as gic_conv2d does; nothing else is written.
+ *   gic_conv_b2b              recomputes conv3 from y2 (C2 channels; w3 act [4*C2, C2]), forms out = relu(bn3(.) + r), r = res (identity
+ *                             shortcut, res_stats == NULL) or bn_res(res) (projection), writes it to block_out act [rows, 4*C2] and feeds
+ *                             it to the next conv1 (w1n act [C1N, 4*C2]): y1n act [rows, C1N] and its column sums into stats1.
+ *                             All BatchNorms on batch statistics over `count` rows.
+ * Both return GIC_STATUS_UNSUPPORTED (nothing launched) in f32 mode and for shapes they have no kernel for (C2 in {64, 128},
+ * C1N in {64, 128}, rows % 64 == 0, enough rows for the streaming kernel): the caller runs gic_conv2d_bn_in + gic_conv1x1_res_in. */
+int gic_conv1x1_bn_in_stats(const void* in, const float* in_stats, int in_nrep, const float* in_gamma, const float* in_beta, float in_count,
+                            const void* w, float* stats, int stats_nrep, int dtype, int64_t rows, int Cin, int Cout, void* stream);
+int gic_conv_b2b(const void* y2, const float* stats2, int nrep2, const float* gamma2, const float* beta2, const void* w3, const float* stats3,
+                 int nrep3, const float* gamma3, const float* beta3, const void* res, const float* res_stats, int res_nrep,
+                 const float* res_gamma, const float* res_beta, float count, void* block_out, const void* w1n, void* y1n, float* stats1,
+                 int nrep1, int dtype, int64_t rows, int C2, int C1N, void* stream);
 /* out = [relu]( bn(y) + (res ? bn_res(res) : 0) ) over rows x C.  A BatchNorm takes its mean/var from `stats` (raw sums over
  * `count` rows; train mode) or from run_mean/run_var (eval mode); res_gamma == NULL -> the residual is added as is. */
 int gic_bn_act(const void* y, const float* stats, const float* gamma, const float* beta, const float* run_mean,

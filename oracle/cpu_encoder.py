@@ -104,7 +104,8 @@ def _bn(x, tp, name, training, running, stats_out, x_stored=None):
 
 def trunk_forward(tp: Dict[str, torch.Tensor], images: torch.Tensor, arch: str, training: bool = True,
                   running: Optional[Dict[str, torch.Tensor]] = None, prefix: str = "encoder.resnet.",
-                  stats_out: Optional[dict] = None, taps: Optional[dict] = None, emulate_bf16: bool = False) -> torch.Tensor:
+                  stats_out: Optional[dict] = None, taps: Optional[dict] = None, emulate_bf16: bool = False,
+                  unstored: Optional[set] = None) -> torch.Tensor:
     """images [N,3,S,S] -> [N, out_features] (global average pool squeezed).
 
     ``emulate_bf16``: the same network with every tensor that the bf16 compute mode STORES rounded to bfloat16 at the point where it
@@ -112,7 +113,9 @@ def trunk_forward(tp: Dict[str, torch.Tensor], images: torch.Tensor, arch: str, 
     from the f32 accumulators, as the kernels' epilogues do), every normalised + ReLU'd activation fed to the next convolution, every
     block output, the pooled feature -- and everything else (products, accumulation, the affine maps, the residual sums) in f32.  It
     separates what bf16 STORAGE does to this network (a property of the data: a pre-BatchNorm tensor whose per-channel |mean| is
-    many times its spread loses that factor in relative precision when the mean is subtracted) from what the kernels do."""
+    many times its spread loses that factor in relative precision when the mean is subtracted) from what the kernels do.
+    ``unstored``: names of convolutions ("4.0.conv3", ...) whose raw output the kernels never store -- it is normalised from the f32
+    accumulators (the conv3 -> block output -> next conv1 launch, TrunkPlan.unstored_convs()): no rounding there."""
     kind, counts, widths, exp = ARCHS[arch]
     P = prefix
     r = _r16 if emulate_bf16 else (lambda t: t)
@@ -120,8 +123,9 @@ def trunk_forward(tp: Dict[str, torch.Tensor], images: torch.Tensor, arch: str, 
     def conv(x, name, stride, pad):
         return F.conv2d(x, r(tp[P + name + ".weight"]), None, stride, pad)
 
-    def bn(y, name):
-        return _bn(y, tp, P + name, training, running, stats_out, x_stored=r(y) if emulate_bf16 else None)
+    def bn(y, name, conv_name=None):
+        keep = unstored is not None and conv_name in unstored
+        return _bn(y, tp, P + name, training, running, stats_out, x_stored=r(y) if (emulate_bf16 and not keep) else None)
 
     x = torch.relu(bn(conv(r(images), "0", 2, 3), "1"))
     x = r(F.max_pool2d(x, 3, 2, 1))
@@ -140,7 +144,7 @@ def trunk_forward(tp: Dict[str, torch.Tensor], images: torch.Tensor, arch: str, 
             else:
                 y = r(torch.relu(bn(conv(x, p + "conv1", 1, 0), p + "bn1")))
                 y = r(torch.relu(bn(conv(y, p + "conv2", stride, 1), p + "bn2")))
-                y = bn(conv(y, p + "conv3", 1, 0), p + "bn3")
+                y = bn(conv(y, p + "conv3", 1, 0), p + "bn3", p + "conv3")
             if stride != 1 or cin != cout:
                 idt = bn(conv(x, p + "downsample.0", stride, 0), p + "downsample.1")
             x = r(torch.relu(y + idt))
