@@ -14,7 +14,7 @@ struct B2bDesc {
   int nrep2, nrep3, res_nrep, nrep1;
   float inv_count;                                                       // 1 / M (all four BatchNorms normalise over the same rows)
   int M;
-  unsigned y2_bytes, res_bytes;
+  unsigned y2_bytes, res_bytes, y1n_bytes = 0;
   int dbg = 0;                                                           // ablation bits (GIC_B2B_DBG, tools only)
 };
 

@@ -30,6 +30,14 @@ namespace {
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// 16-byte accesses through a buffer descriptor: per-lane byte offset + scalar byte offset
+__device__ __forceinline__ u32x4 buf_load16(const __amdgpu_buffer_rsrc_t r, const int voff, const int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store16(const u32x4 v, const __amdgpu_buffer_rsrc_t r, const int voff, const int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+
 // Sum over the 16 lanes of a row (lr) of 16 per-lane values, value e ending up in lane lr == e: a reduce-scatter butterfly, 15 lane
 // exchanges and 15 additions instead of 16 separate registers that live across the whole kernel.
 __device__ __forceinline__ float row_reduce_scatter16(const float (&v)[16], const int lr) {
@@ -61,36 +69,54 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int ntiles = (d.M + BM - 1) / BM;
+  const int ntiles = d.M / BM;
 
   const __amdgpu_buffer_rsrc_t rsW3 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w3, 0, C3 * C2 * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w1n, 0, C1N * C3 * 2, 0x00020000);
   const int wbase = (tid & ~63) * 16;
+  // activations through buffer descriptors too: a 32-bit byte offset per lane and tile, the chunk's offset as the instruction's scalar
+  // offset -- no 64-bit address arithmetic per access (the kernel is bound by instruction issue, not by memory)
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)d.y2, 0, (int)d.y2_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)d.res, 0, (int)d.res_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, (int)d.res_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc(d.y1n, 0, (int)d.y1n_bytes, 0x00020000);
 
   // ---- weight chunk c -> ring stage st_.  LDS images: W3 chunk [64 rows][C2] with LDS row L = 16 j + x holding channel
   //      16 (x >> 2) + 4 j + (x & 3) of the chunk; W1n chunk [C1N rows][64] with LDS row 64 g + 16 jb + x holding output channel
   //      64 g + 16 (x >> 2) + 4 jb + (x & 3); 16-byte pieces XOR-swizzled by (row >> 1) & 7 within each 128 bytes of a row.
-  auto issue_w = [&](const int c, const int st_) {
+  static_assert(PW3 <= 4 && PW1 <= 4, "piece offset arrays");
+  int w3_off[4], w1_off[4];                                              // byte offsets of this thread's pieces inside chunk 0 (literal bounds:
+                                                                         // with [PW3] the host pass silently drops the kernel's instantiation)
+#pragma unroll
+  for (int i = 0; i < PW3; ++i) {
+    const int q = tid + NT * i, L = q / CH3, slot = q % CH3;
+    const int j = L >> 4, x = L & 15, ch = 16 * (x >> 2) + 4 * j + (x & 3);
+    const int kp = (slot & ~7) | ((slot & 7) ^ ((L >> 1) & 7));           // logical 16-byte piece of the row
+    w3_off[i] = (ch * C2 + kp * 8) * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < PW1; ++i) {
+    const int q = tid + NT * i, L = q >> 3, slot = q & 7;
+    const int g = L >> 6, jb = (L >> 4) & 3, x = L & 15, qo = 64 * g + 16 * (x >> 2) + 4 * jb + (x & 3);
+    const int kp = slot ^ ((L >> 1) & 7);
+    w1_off[i] = (qo * C3 + kp * 8) * 2;
+  }
+  auto issue_w_ = [&](const int c, const int st_, const int (&w3o)[4], const int (&w1o)[4]) {
     unsigned char* s0 = smem + st_ * STAGE;
+    // chunk c: W3 rows 64 c .. (64 C2 elements further), W1n columns 64 c ..; c == NC: nothing (zero fill, no traffic)
+    // (the scalar offset is not part of the descriptor's range check: the out-of-range marker goes into the per-lane offset)
     const bool ok = c < NC;
+    const int so3 = ok ? c * (64 * C2 * 2) : 0, so1 = ok ? c * 128 : 0;
+    const int oob = ok ? 0 : (int)0x80000000;                            // OR-ed into the per-lane offset: past every extent
 #pragma unroll
-    for (int i = 0; i < PW3; ++i) {
-      const int q = tid + NT * i, L = q / CH3, slot = q % CH3;
-      const int j = L >> 4, x = L & 15, ch = 16 * (x >> 2) + 4 * j + (x & 3);
-      const int kp = (slot & ~7) | ((slot & 7) ^ ((L >> 1) & 7));         // logical 16-byte piece of the row
-      const unsigned voff = ok ? (unsigned)((c * 64 + ch) * C2 + kp * 8) * 2u : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW3, (lds_void_ptr)(s0 + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, 0);
-    }
+    for (int i = 0; i < PW3; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW3, (lds_void_ptr)(s0 + i * (NT * 16) + wbase), 16, w3o[i] | oob, so3, 0, 0);
 #pragma unroll
-    for (int i = 0; i < PW1; ++i) {
-      const int q = tid + NT * i, L = q >> 3, slot = q & 7;
-      const int g = L >> 6, jb = (L >> 4) & 3, x = L & 15, qo = 64 * g + 16 * (x >> 2) + 4 * jb + (x & 3);
-      const int kp = slot ^ ((L >> 1) & 7);
-      const unsigned voff = ok ? (unsigned)(qo * C3 + c * 64 + kp * 8) * 2u : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (lds_void_ptr)(s0 + W3_BYTES + i * (NT * 16) + wbase), 16, (int)voff, 0, 0, 0);
-    }
+    for (int i = 0; i < PW1; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (lds_void_ptr)(s0 + W3_BYTES + i * (NT * 16) + wbase), 16, w1o[i] | oob, so1, 0, 0);
   };
 
+  auto issue_w = [&](const int c, const int st_) { issue_w_(c, st_, w3_off, w1_off); };
   issue_w(0, 0);
   // ---- coefficient tables
   for (int c = tid; c < C2 + 2 * C3; c += NT) {
@@ -117,24 +143,21 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
     coef2[2 * c] = sc; coef2[2 * c + 1] = sh;                            // (the three tables are contiguous)
   }
 
-  const bf16_t* __restrict__ y2 = (const bf16_t*)d.y2;
-  const bf16_t* __restrict__ res = (const bf16_t*)d.res;
-  bf16_t* __restrict__ out = (bf16_t*)d.out;
-  bf16_t* __restrict__ y1n = (bf16_t*)d.y1n;
-
   float st_s[G2], st_q[G2];                                              // conv1_next's column sums over this wave's pixels, all tiles: lane (lr, lg) holds column 64 g + 16 lg + lr
 #pragma unroll
   for (int g = 0; g < G2; ++g) st_s[g] = st_q[g] = 0.f;
 
   int st = 0;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long m = (long)tile * BM + w * 16 + lr;                        // this lane's pixel
-    const bool mok = m < d.M;
-    const long mc = mok ? m : d.M - 1;                                   // rows past M repeat the last pixel (never stored, never summed)
+    const int m = tile * BM + w * 16 + lr;                               // this lane's pixel (M is a multiple of 64: the launch code)
+    const int yoff = (m * C2 + lg * 8) * 2, roff = (m * C3 + lg * 16) * 2, noff = (m * C1N + lg * 16) * 2;   // byte offsets (< 2^31: the launch code)
     // y2 fragments of the pixel (B operand of conv3: k slots lg * 8 .. + 7 of each 32-deep slice), bn2 + ReLU in registers
     bf16x8 fy[KS1];
 #pragma unroll
-    for (int ks = 0; ks < KS1; ++ks) fy[ks] = *(const bf16x8*)(y2 + mc * C2 + ks * 32 + lg * 8);
+    for (int ks = 0; ks < KS1; ++ks) {
+      const u32x4 t = buf_load16(rsY, yoff, ks * 64);
+      fy[ks] = __builtin_bit_cast(bf16x8, t);
+    }
     f32x4 acc2[G2][4];
 #pragma unroll
     for (int g = 0; g < G2; ++g)
@@ -142,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
       for (int jb = 0; jb < 4; ++jb) acc2[g][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // the shortcut's 16 channels of this pixel in chunk 0 (later chunks: requested at the end of the previous one)
-    u32x4 r0 = *(const u32x4*)(res + mc * C3 + lg * 16), r1 = *(const u32x4*)(res + mc * C3 + lg * 16 + 8);
+    u32x4 r0 = buf_load16(rsR, roff, 0), r1 = buf_load16(rsR, roff + 16, 0);
 #pragma unroll 1
     for (int c = 0; c < NC; ++c) {
       // This thread's weight pieces of chunk c have landed once only what was issued BEHIND them is outstanding (one in-order counter for
@@ -197,12 +220,12 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
       }
       // (rows past M store to the last pixel's address as well: the same values, and the count of outstanding operations stays uniform)
       if (!(d.dbg & 1)) {
-      *(bf16x8*)(out + mc * C3 + c * 64 + lg * 16) = a2[0];
-      *(bf16x8*)(out + mc * C3 + c * 64 + lg * 16 + 8) = a2[1];
+        buf_store16(__builtin_bit_cast(u32x4, a2[0]), rsO, roff, c * 128);
+        buf_store16(__builtin_bit_cast(u32x4, a2[1]), rsO, roff + 16, c * 128);
       }
       if (c + 1 < NC && !(d.dbg & 2)) {
-        r0 = *(const u32x4*)(res + mc * C3 + (c + 1) * 64 + lg * 16);
-        r1 = *(const u32x4*)(res + mc * C3 + (c + 1) * 64 + lg * 16 + 8);
+        r0 = buf_load16(rsR, roff, (c + 1) * 128);
+        r1 = buf_load16(rsR, roff + 16, (c + 1) * 128);
       }
       // ---- conv1_next, transposed: acc2[g][jb] += W1n rows (A operand) x a2 (B operand, k slot (lg, e) <-> chunk channel 16 lg + 8 ks + e)
       if (!(d.dbg & 4))
@@ -229,13 +252,13 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
       for (int e = 0; e < 16; ++e) {
         const float v = acc2[g][e >> 2][e & 3];
         o[e >> 3][e & 7] = (bf16_t)v;
-        vs[e] = mok ? v : 0.f;
-        vq[e] = vs[e] * vs[e];
+        vs[e] = v;
+        vq[e] = v * v;
       }
       st_s[g] += row_reduce_scatter16(vs, lr);
       st_q[g] += row_reduce_scatter16(vq, lr);
-      *(bf16x8*)(y1n + mc * C1N + g * 64 + lg * 16) = o[0];
-      *(bf16x8*)(y1n + mc * C1N + g * 64 + lg * 16 + 8) = o[1];
+      buf_store16(__builtin_bit_cast(u32x4, o[0]), rsN, noff, g * 128);
+      buf_store16(__builtin_bit_cast(u32x4, o[1]), rsN, noff + 16, g * 128);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // a trailing zero-fill DMA must land before the LDS is handed on
@@ -284,11 +307,12 @@ bool launch_b2b(const B2bDesc& d, hipStream_t stream) {
 
 bool try_conv_b2b(const B2bDesc& d, int C2, int C1N, hipStream_t stream) {
   static const bool off = getenv("GIC_NO_CONV_B2B") != nullptr;
-  if (off || d.M <= 0 || d.nrep1 < 1) return false;
+  if (off || d.M <= 0 || d.M % 64 || d.nrep1 < 1) return false;
   static const int dbg = [] { const char* e = getenv("GIC_B2B_DBG"); return e ? atoi(e) : 0; }();
   B2bDesc dd = d; dd.dbg = dbg;
+  dd.y1n_bytes = (unsigned)((long)d.M * C1N * 2);
   const long C3 = 4l * C2;
-  if ((long)d.M * C3 * 2 >= (1l << 40)) return false;
+  if ((long)d.M * C3 * 2 >= (1l << 31)) return false;                    // 32-bit byte offsets into every activation
   for (const void* p : {d.y2, d.w3, d.res, d.w1n, (const void*)d.out, (const void*)d.y1n})
     if (!p || (((uintptr_t)p) & 15)) return false;
   const bool ident = d.res_stats == nullptr;
