@@ -60,7 +60,6 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
   constexpr int PW3 = W3_BYTES / 16 / NT, PW1 = W1_BYTES / 16 / NT;       // DMA pieces per thread and chunk
   constexpr int COEF0 = 2 * STAGE;
   constexpr int ROW3 = C2 * 2, CH3 = ROW3 / 16;                           // bytes / 16-byte pieces of a W3 row (128 | 256 B)
-  constexpr unsigned OOB = 0x80000000u;
   static_assert(PW3 >= 1 && PW1 >= 1, "piece counts");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* coef2 = (float*)(smem + COEF0);                                 // [C2][2]  bn2 scale, shift
@@ -142,38 +141,51 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
     }
     coef2[2 * c] = sc; coef2[2 * c + 1] = sh;                            // (the three tables are contiguous)
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // the table writes are done before this thread reaches the first barrier
 
   float st_s[G2], st_q[G2];                                              // conv1_next's column sums over this wave's pixels, all tiles: lane (lr, lg) holds column 64 g + 16 lg + lr
 #pragma unroll
   for (int g = 0; g < G2; ++g) st_s[g] = st_q[g] = 0.f;
 
-  int st = 0;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int m = tile * BM + w * 16 + lr;                               // this lane's pixel (M is a multiple of 64: the launch code)
-    const int yoff = (m * C2 + lg * 8) * 2, roff = (m * C3 + lg * 16) * 2, noff = (m * C1N + lg * 16) * 2;   // byte offsets (< 2^31: the launch code)
-    // y2 fragments of the pixel (B operand of conv3: k slots lg * 8 .. + 7 of each 32-deep slice), bn2 + ReLU in registers
-    bf16x8 fy[KS1];
+  // ---- loads run AHEAD: the shortcut's 32 bytes of a pixel two chunks ahead (two register pairs, a pair is refilled right after its use,
+  //      across tile boundaries), the next tile's y2 fragments during the current tile's last chunk.  With one chunk of cover every chunk
+  //      waited out a full memory round trip: SQ_WAIT_ANY 59 % of the waves' cycles (tools/trunk_pmc.sh).
+  auto offs = [&](const int tile, int& yoff, int& roff, int& noff) {
+    // byte offsets of this lane's pixel (M is a multiple of 64 and every tensor is below 2 GiB: the launch code); past the last tile:
+    // the out-of-range marker (loads return zero without traffic, the count of outstanding operations stays uniform)
+    const int m = tile * BM + w * 16 + lr;
+    const int oob = tile < ntiles ? 0 : (int)0x80000000;
+    yoff = ((m * C2 + lg * 8) * 2) | oob; roff = ((m * C3 + lg * 16) * 2) | oob; noff = ((m * C1N + lg * 16) * 2) | oob;
+  };
+  int yoff, roff, noff;
+  offs(blockIdx.x, yoff, roff, noff);
+  bf16x8 fy[KS1], fyn[KS1];
 #pragma unroll
-    for (int ks = 0; ks < KS1; ++ks) {
-      const u32x4 t = buf_load16(rsY, yoff, ks * 64);
-      fy[ks] = __builtin_bit_cast(bf16x8, t);
-    }
+  for (int ks = 0; ks < KS1; ++ks) fyn[ks] = __builtin_bit_cast(bf16x8, buf_load16(rsY, yoff, ks * 64));
+  u32x4 ra0 = buf_load16(rsR, roff, 0), ra1 = buf_load16(rsR, roff + 16, 0);          // chunk 0 (even chunks: pair a)
+  u32x4 rb0 = buf_load16(rsR, roff, 128), rb1 = buf_load16(rsR, roff + 16, 128);      // chunk 1 (odd chunks: pair b)
+
+  int st = 0;
+  bool first = true;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int yoff_n, roff_n, noff_n;
+    offs(tile + gridDim.x, yoff_n, roff_n, noff_n);
     f32x4 acc2[G2][4];
 #pragma unroll
     for (int g = 0; g < G2; ++g)
 #pragma unroll
       for (int jb = 0; jb < 4; ++jb) acc2[g][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // the shortcut's 16 channels of this pixel in chunk 0 (later chunks: requested at the end of the previous one)
-    u32x4 r0 = buf_load16(rsR, roff, 0), r1 = buf_load16(rsR, roff + 16, 0);
-#pragma unroll 1
-    for (int c = 0; c < NC; ++c) {
+    auto chunk = [&](const int c, u32x4& r0, u32x4& r1) {
       // This thread's weight pieces of chunk c have landed once only what was issued BEHIND them is outstanding (one in-order counter for
-      // loads, LDS-DMA and stores): the previous chunk's two block-output stores and this chunk's two shortcut loads -- at a tile's first
-      // chunk also the previous tile's y1n stores and this tile's y2 loads.  Nothing waits for a store to complete.
-      if (c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 2 * G2 + KS1) : "memory");
+      // loads, LDS-DMA and stores): the previous chunk's two block-output stores and two shortcut loads -- behind a tile's last chunk also
+      // its y1n stores and the next tile's y2 loads.  Nothing waits for a store to complete.
+      // (the workgroup's very first chunk: only the prologue's y2 and shortcut loads are behind its weight pieces)
+      if (c == 0 && first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + KS1) : "memory");
+      else if (c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 2 * G2 + KS1) : "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      __syncthreads();                                                   // chunk c's stage (and, the first time, the tables) visible; stage st ^ 1 is free
+      __builtin_amdgcn_s_barrier();                                      // chunk c's stage (and, the first time, the tables) visible; stage st ^ 1 is free
+      asm volatile("" ::: "memory");
       issue_w(c + 1 < NC ? c + 1 : (tile + (int)gridDim.x < ntiles ? 0 : NC), st ^ 1);   // the next chunk (of the next tile; none after the last)
       if (c == 0) {
 #pragma unroll
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
           const float scl[8] = {c0.x, c0.z, c1.x, c1.z, c2.x, c2.z, c3.x, c3.z};
           const float sft[8] = {c0.y, c0.w, c1.y, c1.w, c2.y, c2.w, c3.y, c3.w};
 #pragma unroll
-          for (int e = 0; e < 8; ++e) fy[ks][e] = (bf16_t)fmaxf((float)fy[ks][e] * scl[e] + sft[e], 0.f);
+          for (int e = 0; e < 8; ++e) fy[ks][e] = (bf16_t)fmaxf((float)fyn[ks][e] * scl[e] + sft[e], 0.f);
         }
       }
       const unsigned char* sW3 = smem + st * STAGE;
@@ -218,17 +230,16 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
         a2[e >> 3][e & 7] = (bf16_t)v0;
         a2[(e + 1) >> 3][(e + 1) & 7] = (bf16_t)v1;
       }
-      // (rows past M store to the last pixel's address as well: the same values, and the count of outstanding operations stays uniform)
-      if (!(d.dbg & 1)) {
-        buf_store16(__builtin_bit_cast(u32x4, a2[0]), rsO, roff, c * 128);
-        buf_store16(__builtin_bit_cast(u32x4, a2[1]), rsO, roff + 16, c * 128);
+      if (c == NC - 1) {                                                 // the next tile's y2 fragments (behind this chunk's weight pieces)
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) fyn[ks] = __builtin_bit_cast(bf16x8, buf_load16(rsY, yoff_n, ks * 64));
       }
-      if (c + 1 < NC && !(d.dbg & 2)) {
-        r0 = buf_load16(rsR, roff, (c + 1) * 128);
-        r1 = buf_load16(rsR, roff + 16, (c + 1) * 128);
-      }
+      buf_store16(__builtin_bit_cast(u32x4, a2[0]), rsO, roff, c * 128);
+      buf_store16(__builtin_bit_cast(u32x4, a2[1]), rsO, roff + 16, c * 128);
+      // refill this pair: the shortcut of chunk c + 2 (of the next tile behind the last two chunks)
+      if (c + 2 < NC) { r0 = buf_load16(rsR, roff, (c + 2) * 128); r1 = buf_load16(rsR, roff + 16, (c + 2) * 128); }
+      else { r0 = buf_load16(rsR, roff_n, (c + 2 - NC) * 128); r1 = buf_load16(rsR, roff_n + 16, (c + 2 - NC) * 128); }
       // ---- conv1_next, transposed: acc2[g][jb] += W1n rows (A operand) x a2 (B operand, k slot (lg, e) <-> chunk channel 16 lg + 8 ks + e)
-      if (!(d.dbg & 4))
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -241,8 +252,12 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
           }
       }
       st ^= 1;
+    };
+#pragma unroll 1
+    for (int c = 0; c < NC; c += 2) {
+      chunk(c, ra0, ra1);
+      chunk(c + 1, rb0, rb1);
     }
-    if (d.dbg & 1) continue;
     // ---- y1n: lane (lr, lg) holds output channels 64 g + 16 lg + 4 jb + r of its pixel: 32 contiguous bytes per g
 #pragma unroll
     for (int g = 0; g < G2; ++g) {
@@ -260,6 +275,8 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
       buf_store16(__builtin_bit_cast(u32x4, o[0]), rsN, noff, g * 128);
       buf_store16(__builtin_bit_cast(u32x4, o[1]), rsN, noff + 16, g * 128);
     }
+    yoff = yoff_n; roff = roff_n; noff = noff_n;
+    first = false;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // a trailing zero-fill DMA must land before the LDS is handed on
 
