@@ -54,11 +54,19 @@ __device__ __forceinline__ float row_reduce_scatter16(const float (&v)[16], cons
 
 // C2: channels of y2 (64 | 128); C1N: output channels of the next conv1 (64 | 128); IDENT: identity shortcut (no BatchNorm of its own)
 template <int C2, int C1N, bool IDENT>
-__global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
-  constexpr int NT = 256, NW = NT / 64, BM = 16 * NW, C3 = 4 * C2, NC = C3 / 64, KS1 = C2 / 32, G2 = C1N / 64;
+__global__ __launch_bounds__(512) void conv_b2b_kernel(const B2bDesc d) {
+  // RES (C2 == 64: the 56 x 56 boundaries): ALL weight chunks resident in LDS (64 / 96 KB), loaded once per persistent workgroup of eight
+  // waves -- no DMA, no wait and no barrier inside the loop, the waves run free.  Otherwise (C2 == 128: 256 KB of weights) a THREE-stage
+  // ring with one barrier per chunk: the weight pieces of chunk c + 2 are issued during chunk c.  (Loads return in order: with a
+  // two-stage ring the L2-resident weight pieces of the next chunk sat in the queue behind the shortcut loads issued just before
+  // them, which come from HBM, and every chunk's wait for its weights inherited a memory round trip.)
+  constexpr bool RES = C2 == 64;
+  constexpr int NSTG = 3;
+  constexpr int NT = 512, NW = NT / 64, BM = 16 * NW, C3 = 4 * C2, NC = C3 / 64, KS1 = C2 / 32, G2 = C1N / 64;
   constexpr int W3_BYTES = 64 * C2 * 2, W1_BYTES = C1N * 128, STAGE = W3_BYTES + W1_BYTES;
   constexpr int PW3 = W3_BYTES / 16 / NT, PW1 = W1_BYTES / 16 / NT;       // DMA pieces per thread and chunk
-  constexpr int COEF0 = 2 * STAGE;
+  constexpr int COEF0 = (RES ? NC : NSTG) * STAGE;
+  constexpr int PW = PW3 + PW1;
   constexpr int ROW3 = C2 * 2, CH3 = ROW3 / 16;                           // bytes / 16-byte pieces of a W3 row (128 | 256 B)
   static_assert(PW3 >= 1 && PW1 >= 1, "piece counts");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -116,7 +124,13 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
   };
 
   auto issue_w = [&](const int c, const int st_) { issue_w_(c, st_, w3_off, w1_off); };
-  issue_w(0, 0);
+  if constexpr (RES) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) issue_w(c, c);
+  } else {
+    issue_w(0, 0);
+    issue_w(1, 1);
+  }
   // ---- coefficient tables
   for (int c = tid; c < C2 + 2 * C3; c += NT) {
     float sc, sh;
@@ -142,6 +156,11 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
     coef2[2 * c] = sc; coef2[2 * c + 1] = sh;                            // (the three tables are contiguous)
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // the table writes are done before this thread reaches the first barrier
+  if constexpr (RES) {                                                   // ... and its weight pieces have landed: the one barrier of the resident form
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
 
   float st_s[G2], st_q[G2];                                              // conv1_next's column sums over this wave's pixels, all tiles: lane (lr, lg) holds column 64 g + 16 lg + lr
 #pragma unroll
@@ -181,12 +200,21 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
       // loads, LDS-DMA and stores): the previous chunk's two block-output stores and two shortcut loads -- behind a tile's last chunk also
       // its y1n stores and the next tile's y2 loads.  Nothing waits for a store to complete.
       // (the workgroup's very first chunk: only the prologue's y2 and shortcut loads are behind its weight pieces)
-      if (c == 0 && first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + KS1) : "memory");
-      else if (c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 2 * G2 + KS1) : "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                      // chunk c's stage (and, the first time, the tables) visible; stage st ^ 1 is free
-      asm volatile("" ::: "memory");
-      issue_w(c + 1 < NC ? c + 1 : (tile + (int)gridDim.x < ntiles ? 0 : NC), st ^ 1);   // the next chunk (of the next tile; none after the last)
+      if constexpr (!RES) {
+        // Behind chunk c's weight pieces (issued two chunks ago): per chunk 2 stores + 2 shortcut loads, the next chunk's PW pieces; around
+        // a tile boundary also the y1n stores and the next tile's y2 loads; in the workgroup's first two chunks the prologue's loads.
+        if (first && c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + KS1 + 4) : "memory");
+        else if (first && c == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS1 + 8 + PW) : "memory");
+        else if (c < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + PW + KS1 + 2 * G2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + PW) : "memory");
+        __builtin_amdgcn_s_barrier();                                    // chunk c's stage (and, the first time, the tables) visible; the stage of chunk c - 1 is free
+        asm volatile("" ::: "memory");
+        {                                                                // chunk c + 2 (of the next tile; none behind the last tile)
+          const bool more = tile + (int)gridDim.x < ntiles;
+          const int cn = c + 2 < NC ? c + 2 : (more ? c + 2 - NC : NC);
+          issue_w(cn, st >= 1 ? st - 1 : NSTG - 1);                      // (st + 2) % 3
+        }
+      }
       if (c == 0) {
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
@@ -198,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
           for (int e = 0; e < 8; ++e) fy[ks][e] = (bf16_t)fmaxf((float)fyn[ks][e] * scl[e] + sft[e], 0.f);
         }
       }
-      const unsigned char* sW3 = smem + st * STAGE;
+      const unsigned char* sW3 = smem + (RES ? c : st) * STAGE;
       const unsigned char* sW1 = sW3 + W3_BYTES;
       // ---- conv3, transposed: block j, MFMA row x <-> channel 16 (x >> 2) + 4 j + (x & 3): lane (lr, lg) ends up with channels 16 lg + 4 j + r
       f32x4 acc1[4];
@@ -251,7 +279,7 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
             acc2[g][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, a2[ks], acc2[g][jb], 0, 0, 0);
           }
       }
-      st ^= 1;
+      st = st == NSTG - 1 ? 0 : st + 1;
     };
 #pragma unroll 1
     for (int c = 0; c < NC; c += 2) {
@@ -304,19 +332,22 @@ __global__ __launch_bounds__(256) void conv_b2b_kernel(const B2bDesc d) {
 template <int C2, int C1N, bool IDENT>
 bool launch_b2b(const B2bDesc& d, hipStream_t stream) {
   constexpr int C3 = 4 * C2;
-  constexpr size_t lds = 2 * (64 * C2 * 2 + C1N * 128) + (size_t)(C2 + 2 * C3) * 8;
+  constexpr bool RES = C2 == 64;
+  constexpr int NT = 512;
+  constexpr size_t lds = (RES ? C3 / 64 : 3) * (size_t)(64 * C2 * 2 + C1N * 128) + (size_t)(C2 + 2 * C3) * 8;
   static_assert(lds <= 160 * 1024, "conv_b2b LDS budget");
   static LdsGrant granted;
   if (!grant_lds(conv_b2b_kernel<C2, C1N, IDENT>, lds, granted)) return false;
-  static const int per_cu = [] { const char* e = getenv("GIC_B2B_WG_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 2; }();
+  // persistent workgroups per CU: as many as the LDS lets share a CU, two at most (measured: 3 and 4 lose)
+  static const int per_cu = [] { const char* e = getenv("GIC_B2B_WG_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : (lds > 80 * 1024 ? 1 : 2); }();
   static const int cus = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 256; }
     return n;
   }();
-  const int tiles = cdiv(d.M, 64);
+  const int tiles = d.M / (NT / 4);
   const int grid = tiles < cus * per_cu ? tiles : cus * per_cu;
-  hipLaunchKernelGGL((conv_b2b_kernel<C2, C1N, IDENT>), dim3((unsigned)grid), dim3(256), lds, stream, d);
+  hipLaunchKernelGGL((conv_b2b_kernel<C2, C1N, IDENT>), dim3((unsigned)grid), dim3(NT), lds, stream, d);
   return true;
 }
 
@@ -324,7 +355,7 @@ bool launch_b2b(const B2bDesc& d, hipStream_t stream) {
 
 bool try_conv_b2b(const B2bDesc& d, int C2, int C1N, hipStream_t stream) {
   static const bool off = getenv("GIC_NO_CONV_B2B") != nullptr;
-  if (off || d.M <= 0 || d.M % 64 || d.nrep1 < 1) return false;
+  if (off || d.M <= 0 || d.M % 128 || d.nrep1 < 1) return false;
   static const int dbg = [] { const char* e = getenv("GIC_B2B_DBG"); return e ? atoi(e) : 0; }();
   B2bDesc dd = d; dd.dbg = dbg;
   dd.y1n_bytes = (unsigned)((long)d.M * C1N * 2);

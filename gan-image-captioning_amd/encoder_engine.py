@@ -102,8 +102,8 @@ class TrunkPlan:
         # ... and, where the kernels exist, WITHOUT conv3's output ever reaching memory: conv3 runs as a statistics-only pass and is
         # recomputed inside the launch that forms the block output and runs the next conv1 (gic_conv_b2b; GIC_NO_CONV_B2B=1: off)
         self.fuse_b2b = not os.environ.get("GIC_NO_CONV_B2B")
-        self.b2b_only = int(os.environ.get("GIC_B2B_ONLY", "2"))     # 0 = every boundary the kernels take, 1 = the 28 x 28 blocks only, 2 = all but
-        # the 56 x 56 boundary into 128 output channels (measured slower there: 83 us against 56 + 6)
+        self.b2b_only = int(os.environ.get("GIC_B2B_ONLY", "0"))     # tuning: 0 = every boundary the kernels take, 1 = the 28 x 28 blocks only,
+        # 2 = all but the 56 x 56 boundary into 128 output channels
         self._nrep = {}
         self.use_graph = not os.environ.get("GIC_NO_GRAPH")
         self.pending_tracked = 0
