@@ -369,6 +369,7 @@ bool try_conv_b2b(const B2bDesc& d, int C2, int C1N, hipStream_t stream) {
   if (C2 == 64 && C1N == 64) return ident ? launch_b2b<64, 64, true>(dd, stream) : launch_b2b<64, 64, false>(dd, stream);
   if (C2 == 64 && C1N == 128) return ident ? launch_b2b<64, 128, true>(dd, stream) : launch_b2b<64, 128, false>(dd, stream);
   if (C2 == 128 && C1N == 128) return ident ? launch_b2b<128, 128, true>(dd, stream) : launch_b2b<128, 128, false>(dd, stream);
+  if (C2 == 128 && C1N == 256) return ident ? launch_b2b<128, 256, true>(dd, stream) : launch_b2b<128, 256, false>(dd, stream);
   return false;
 }
 

@@ -496,7 +496,7 @@ def test_block_output_formed_on_load_equals_the_separate_pass(dev):
 def test_conv3_recomputed_inside_the_next_conv1_equals_the_separate_launches(dev):
     """gic_conv1x1_bn_in_stats + gic_conv_b2b (conv3 as a statistics-only pass, then recomputed inside the launch that forms the block
     output and runs the next block's conv1: its output never reaches memory) against the separate launches (conv3 writes y3, the next
-    conv1 forms the block output on load): ResNet-50 at the BASELINE shape (64 images, 224 x 224, bf16), six block boundaries on the
+    conv1 forms the block output on load): ResNet-50 at the BASELINE shape (64 images, 224 x 224, bf16), seven block boundaries on the
     56 x 56 and 28 x 28 maps take the fused form; every block output, the pooled feature and the running statistics agree to bf16
     rounding (the fused form never rounds y3 to bf16: it is the more accurate of the two)."""
     from gan_image_captioning_amd.trunk import ResNetTrunk
@@ -520,7 +520,7 @@ def test_conv3_recomputed_inside_the_next_conv1_equals_the_separate_launches(dev
         nb2b = sum(1 for blk in plan.blocks if blk.get("b2b") is True)
         sd = trunk.state_dict()
         outs[fused] = (feat, blocks, nb2b, sd["5.1.bn1.running_var"].float().clone(), sd["7.2.bn3.running_var"].float().clone())
-    assert outs[True][2] == 6 and outs[False][2] == 0, (outs[True][2], outs[False][2])
+    assert outs[True][2] == 7 and outs[False][2] == 0, (outs[True][2], outs[False][2])
     errs = [rel_l2(a, b_) for a, b_ in zip(outs[True][1], outs[False][1])]
     report = " ".join(f"{e:.2e}" for e in errs) + (f" | pooled {rel_l2(outs[True][0], outs[False][0]):.2e} running_var "
                                                     f"{rel_l2(outs[True][3], outs[False][3]):.2e} {rel_l2(outs[True][4], outs[False][4]):.2e}")

@@ -284,7 +284,7 @@ def test_cfg2_composed_step_bf16_vs_oracle():
     with torch.no_grad():
         feat = OE.trunk_forward(tp, images, "resnet50", taps=taps)
         # bf16 STORAGE emulated on the CPU (round 3); conv3 of these blocks is normalised from its f32 accumulators (gic_conv_b2b)
-        unstored = {"4.0.conv3", "4.1.conv3", "4.2.conv3", "5.0.conv3", "5.1.conv3", "5.2.conv3"}
+        unstored = {"4.0.conv3", "4.1.conv3", "4.2.conv3", "5.0.conv3", "5.1.conv3", "5.2.conv3", "5.3.conv3"}
         feat16 = OE.trunk_forward(tp, images, "resnet50", taps=taps16, emulate_bf16=True, unstored=unstored)
     ref = O.adv_step(dict(gp), dict(dp), caps, us, masks, T, "standard", 5.0, None, None, trunk_feat=feat)
 
