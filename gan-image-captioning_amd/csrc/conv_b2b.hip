@@ -364,8 +364,6 @@ bool try_conv_b2b(const B2bDesc& d, int C2, int C1N, hipStream_t stream) {
   for (const void* p : {d.y2, d.w3, d.res, d.w1n, (const void*)d.out, (const void*)d.y1n})
     if (!p || (((uintptr_t)p) & 15)) return false;
   const bool ident = d.res_stats == nullptr;
-  static const int only = [] { const char* e = getenv("GIC_B2B_ONLY"); return e ? atoi(e) : 0; }();      // tuning: 1 = C2 == 128 only, 2 = all but (64, 128)
-  if ((only == 1 && C2 != 128) || (only == 2 && C2 == 64 && C1N == 128)) return false;
   if (C2 == 64 && C1N == 64) return ident ? launch_b2b<64, 64, true>(dd, stream) : launch_b2b<64, 64, false>(dd, stream);
   if (C2 == 64 && C1N == 128) return ident ? launch_b2b<64, 128, true>(dd, stream) : launch_b2b<64, 128, false>(dd, stream);
   if (C2 == 128 && C1N == 128) return ident ? launch_b2b<128, 128, true>(dd, stream) : launch_b2b<128, 128, false>(dd, stream);
