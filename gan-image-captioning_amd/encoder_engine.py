@@ -285,7 +285,7 @@ class TrunkPlan:
         if (self.b2b_only == 1 and c2.cout != 128) or (self.b2b_only == 2 and (c2.cout, c1n.cout) == (64, 128)):
             return False
         return (c3.k == 1 and c3.stride == 1 and c1n.k == 1 and c1n.stride == 1 and c3.cout == 4 * c2.cout and c1n.cin == c3.cout and
-                (c2.cout, c1n.cout) in ((64, 64), (64, 128), (128, 128), (128, 256)) and rows_ % 64 == 0 and rows_ >= self.res_min_rows)
+                (c2.cout, c1n.cout) in ((64, 64), (64, 128), (128, 128), (128, 256)) and rows_ % 128 == 0 and rows_ >= self.res_min_rows)
 
     def _conv3_stats_only(self, blk: dict, y2, stats, rows_c2: int, rows_: int) -> bool:
         c2, c3 = blk["c2"], blk["c3"]

@@ -531,6 +531,35 @@ def test_conv3_recomputed_inside_the_next_conv1_equals_the_separate_launches(dev
     assert rel_l2(outs[True][3], outs[False][3]) < 1e-2 and rel_l2(outs[True][4], outs[False][4]) < 5e-2, report
 
 
+@pytest.mark.parametrize("N,expect", [(17, 0), (20, 0), (24, 3)])
+def test_back_to_back_launches_engage_only_where_their_kernels_take_the_shapes(dev, N, expect):
+    """Batch sizes around the fused form's conditions (rows a multiple of 128, enough row tiles for the statistics-only pass, >= 50 000
+    rows): 17 images (53 312 rows at 56 x 56: not a multiple of 128) and 20 (62 720 rows: 980 tiles, below the streaming kernel's
+    minimum) stay on the separate launches, 24 fuses the three 56 x 56 boundaries only (18 816 rows at 28 x 28); every plan runs and
+    agrees with the unfused plan."""
+    from gan_image_captioning_amd.trunk import ResNetTrunk
+    g = torch.Generator().manual_seed(29)
+    tp = OE.make_trunk_params("resnet50", g)
+    images = torch.randn(N, 3, 224, 224, generator=g).to(dev)
+    feats = {}
+    for fused in (True, False):
+        trunk = ResNetTrunk("resnet50")
+        trunk.load_state_dict({k[len("encoder.resnet."):]: v for k, v in tp.items()}, strict=False)
+        trunk = trunk.to(dev).train()
+        trunk(images, 1)
+        plan = trunk._plan
+        plan.fuse_b2b = fused
+        plan.use_graph = False
+        for blk in plan.blocks:
+            blk.pop("b2b", None)
+        feats[fused] = trunk(images, 1).float().clone()
+        torch.cuda.synchronize()
+        if fused:
+            assert len(plan.unstored_convs()) == expect, (N, plan.unstored_convs())
+    assert torch.isfinite(feats[True]).all()
+    assert rel_l2(feats[True], feats[False]) < 3e-2
+
+
 def test_cold_and_mispredicted_trunk_passes_do_not_race_the_lookahead(dev):
     """A synchronous trunk pass (the first batch of a loop, or the pass after a mispredicted look-ahead) shares the plan's buffers
     (packed image, statistics arena, activations, pooled output) with the look-ahead pass that is enqueued right behind it on
