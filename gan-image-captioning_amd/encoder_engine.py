@@ -277,7 +277,7 @@ class TrunkPlan:
 
     def _b2b_ok(self, blk: dict, nxt: Optional[dict], rows_: int, training: bool) -> bool:
         """conv3 of `blk` + the block output + conv1 of `nxt` as gic_conv1x1_bn_in_stats + gic_conv_b2b (shapes the kernels exist for)."""
-        if not (training and self.fuse_res and self.fuse_b2b and self.fuse_in and self.dtype != L.F32) or nxt is None or blk.get("b2b") is False:
+        if not (training and self.fuse_res and self.fuse_b2b and self.fuse_in and self.dtype != L.F32) or nxt is None or rows_ in blk.get("b2b_refused", ()):
             return False
         if blk["kind"] != "bottleneck" or nxt["kind"] != "bottleneck":
             return False
@@ -298,6 +298,7 @@ class TrunkPlan:
             if self.conv_trace:
                 self.conv_trace.pop()
             blk["b2b"] = False
+            blk.setdefault("b2b_refused", set()).add(rows_)        # (this row count only: another batch size is probed again)
             return False
         _check(status, "gic_conv1x1_bn_in_stats " + c3.name)
         blk["b2b"] = True
@@ -434,6 +435,7 @@ class TrunkPlan:
                 # not once per tap; the library declines the stride-2 ones: bn_act + plain convolution), bn2 + ReLU into conv3
                 self._bn_relu_conv(c1, e["y1"], e["z1"], c2, e["y2"], stats, training, N, hin, hin, rows[c1.name])
                 b2b = self._b2b_ok(blk, nxt, rows[c3.name], training) and self._conv3_stats_only(blk, e["y2"], stats, rows[c2.name], rows[c3.name])
+                blk["b2b"] = bool(b2b)                                   # (what this pass did: unstored_convs(), conv_shapes())
                 if not b2b:
                     self._bn_relu_conv(c2, e["y2"], e["z2"], c3, e["y3"], stats, training, N, ho, ho, rows[c2.name])
                 last, ylast = c3, e["y3"]

@@ -513,7 +513,7 @@ def test_conv3_recomputed_inside_the_next_conv1_equals_the_separate_launches(dev
         plan.fuse_b2b = fused
         plan.use_graph = False
         for blk in plan.blocks:
-            blk.pop("b2b", None)                           # re-probe
+            blk.pop("b2b", None); blk.pop("b2b_refused", None)   # re-probe
         feat = trunk(images, 1).float().clone()
         torch.cuda.synchronize()
         blocks = [e["out"].float().clone() for e in plan._bufs[(64, 224)]["blocks"]]
@@ -551,7 +551,7 @@ def test_back_to_back_launches_engage_only_where_their_kernels_take_the_shapes(d
         plan.fuse_b2b = fused
         plan.use_graph = False
         for blk in plan.blocks:
-            blk.pop("b2b", None)
+            blk.pop("b2b", None); blk.pop("b2b_refused", None)
         feats[fused] = trunk(images, 1).float().clone()
         torch.cuda.synchronize()
         if fused:
