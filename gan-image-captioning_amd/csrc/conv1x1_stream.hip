@@ -119,13 +119,14 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const StreamDesc d)
   // ---- row tiles grp, grp + groups, ...: ring stage of the j-th = j % NS
   constexpr int CPR = BN / 8;                                            // 16-byte chunks per C tile row
   auto store_tile = [&](const int bm0, const unsigned char* buf) {
+    if (d.stats_only) return;                                            // the statistics-only pass writes (and stages) nothing
 #pragma unroll
     for (int i = 0; i < CS; ++i) {
       const int c = tid + NT * i;
       const int ml = c / CPR, cc = c % CPR;
       const int m = bm0 + ml, n = bn0 + cc * 8;
       const u32x4 v = *(const u32x4*)(buf + ml * SC + cc * 16);
-      if (m < M && n < N && !d.stats_only) *(u32x4*)(C + (long)m * d.ldc + n) = v;      // (a wave skips a store only in its last, partial row tile)
+      if (m < M && n < N) *(u32x4*)(C + (long)m * d.ldc + n) = v;      // (a wave skips a store only in its last, partial row tile)
     }
   };
   int st = 0, jj = 0, prev_bm0 = 0;
@@ -133,7 +134,9 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const StreamDesc d)
     const int bm0 = tile * BM;
     // A tile j has landed once all but the DMAs and stores issued after it are done.  Per iteration a thread issues the DMA of the tile
     // NS - 1 ahead (CA pieces), then the stores of a C tile (CS; double-buffered C: of the PREVIOUS tile, so iteration 0 has none).
-    if constexpr (DBUF) {      // NS = 4: behind tile j came 2 tiles' DMAs and the stores of iterations max(1, j - 3) .. j - 1
+    if (d.stats_only) {        // no stores in the queue: only the DMAs issued behind tile j may be outstanding
+      if constexpr (DBUF) wait_vm<2 * CA>(); else wait_vm<0>();
+    } else if constexpr (DBUF) {      // NS = 4: behind tile j came 2 tiles' DMAs and the stores of iterations max(1, j - 3) .. j - 1
       if (jj <= 1) wait_vm<2 * CA>();
       else if (jj == 2) wait_vm<2 * CA + CS>();
       else if (jj == 3) wait_vm<2 * CA + 2 * CS>();
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const StreamDesc d)
         for (int r = 0; r < 4; ++r) {
           const int ml = wr * 32 + i * 16 + lg * 4 + r;
           const float v = acc[i][j][r];
-          *(bf16_t*)(sCj + ml * SC + nl * 2) = (bf16_t)v;
+          if (!d.stats_only) *(bf16_t*)(sCj + ml * SC + nl * 2) = (bf16_t)v;
           if (bm0 + ml < M) { st_s[j] += v; st_q[j] += v * v; }
         }
       }
