@@ -15,7 +15,6 @@ struct B2bDesc {
   float inv_count;                                                       // 1 / M (all four BatchNorms normalise over the same rows)
   int M;
   unsigned y2_bytes, res_bytes, y1n_bytes = 0;
-  int dbg = 0;                                                           // ablation bits (GIC_B2B_DBG, tools only)
 };
 
 // false: shapes it has no instantiation for (the caller runs the separate launches)

@@ -356,8 +356,7 @@ bool launch_b2b(const B2bDesc& d, hipStream_t stream) {
 bool try_conv_b2b(const B2bDesc& d, int C2, int C1N, hipStream_t stream) {
   static const bool off = getenv("GIC_NO_CONV_B2B") != nullptr;
   if (off || d.M <= 0 || d.M % 128 || d.nrep1 < 1) return false;
-  static const int dbg = [] { const char* e = getenv("GIC_B2B_DBG"); return e ? atoi(e) : 0; }();
-  B2bDesc dd = d; dd.dbg = dbg;
+  B2bDesc dd = d;
   dd.y1n_bytes = (unsigned)((long)d.M * C1N * 2);
   const long C3 = 4l * C2;
   if ((long)d.M * C3 * 2 >= (1l << 31)) return false;                    // 32-bit byte offsets into every activation
