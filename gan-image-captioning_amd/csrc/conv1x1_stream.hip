@@ -34,8 +34,10 @@ struct StreamDesc {
   unsigned a_bytes, b_bytes;
 };
 
-// BN output channels per workgroup; KT = K / 64; ABN: BatchNorm + ReLU of the input on load
-template <int BN, int KT, bool ABN>
+// BN output channels per workgroup; KT = K / 64; ABN: BatchNorm + ReLU of the input on load; STATS: the column sums ONLY (the first pass of
+// conv_b2b.hip's pair: no C tile in LDS, no stores -- which leaves room for 256 output channels per workgroup, so that a row tile is
+// fetched and normalised once for all of them)
+template <int BN, int KT, bool ABN, bool STATS = false>
 __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const StreamDesc d) {
   constexpr int BM = 128, NT = 512, K = 64 * KT;
   constexpr int NS = KT == 1 ? 4 : 2;                                   // ring stages of A tiles (NS - 1 tiles in flight)
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const StreamDesc d)
   constexpr int A_BYTES = KT * BM * 128, W_BYTES = KT * BN * 128;
   constexpr int SC = BN * 2 + 16, C_BYTES = BM * SC;
   constexpr bool DBUF = KT == 1;                                        // two C tiles: one barrier per row tile, the stores of a tile run under the next tile's MFMAs
-  constexpr int W0 = NS * A_BYTES, C0 = W0 + W_BYTES, ST0 = C0 + (DBUF ? 2 : 1) * C_BYTES, COEF0 = ST0 + 4 * BN * 2 * 4;
+  constexpr int W0 = NS * A_BYTES, C0 = W0 + W_BYTES, ST0 = C0 + (STATS ? 0 : (DBUF ? 2 : 1) * C_BYTES), COEF0 = ST0 + 4 * BN * 2 * 4;
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const StreamDesc d)
   // ---- row tiles grp, grp + groups, ...: ring stage of the j-th = j % NS
   constexpr int CPR = BN / 8;                                            // 16-byte chunks per C tile row
   auto store_tile = [&](const int bm0, const unsigned char* buf) {
-    if (d.stats_only) return;                                            // the statistics-only pass writes (and stages) nothing
+    if constexpr (STATS) return;                                         // the statistics-only pass writes (and stages) nothing
 #pragma unroll
     for (int i = 0; i < CS; ++i) {
       const int c = tid + NT * i;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const StreamDesc d)
     const int bm0 = tile * BM;
     // A tile j has landed once all but the DMAs and stores issued after it are done.  Per iteration a thread issues the DMA of the tile
     // NS - 1 ahead (CA pieces), then the stores of a C tile (CS; double-buffered C: of the PREVIOUS tile, so iteration 0 has none).
-    if (d.stats_only) {        // no stores in the queue: only the DMAs issued behind tile j may be outstanding
+    if (STATS) {               // no stores in the queue: only the DMAs issued behind tile j may be outstanding
       if constexpr (DBUF) wait_vm<2 * CA>(); else wait_vm<0>();
     } else if constexpr (DBUF) {      // NS = 4: behind tile j came 2 tiles' DMAs and the stores of iterations max(1, j - 3) .. j - 1
       if (jj <= 1) wait_vm<2 * CA>();
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const StreamDesc d)
     // the tile NS - 1 ahead goes into the stage that the previous tile occupied
     issue_a(tile + (NS - 1) * d.groups, st == 0 ? NS - 1 : st - 1);
     unsigned char* sCj = sC + (DBUF ? (jj & 1) * C_BYTES : 0);
-    if constexpr (DBUF) {
+    if constexpr (DBUF && !STATS) {
       if (jj > 0) store_tile(prev_bm0, sC + ((jj - 1) & 1) * C_BYTES);   // runs under this tile's MFMAs
     }
     f32x4 acc[TM][TN];
@@ -202,12 +204,12 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const StreamDesc d)
         for (int r = 0; r < 4; ++r) {
           const int ml = wr * 32 + i * 16 + lg * 4 + r;
           const float v = acc[i][j][r];
-          if (!d.stats_only) *(bf16_t*)(sCj + ml * SC + nl * 2) = (bf16_t)v;
+          if constexpr (!STATS) *(bf16_t*)(sCj + ml * SC + nl * 2) = (bf16_t)v;
           if (bm0 + ml < M) { st_s[j] += v; st_q[j] += v * v; }
         }
       }
     }
-    if constexpr (!DBUF) {
+    if constexpr (!DBUF && !STATS) {
       __syncthreads();
       store_tile(bm0, sCj);
     }
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const StreamDesc d)
     ++jj;
     st = st == NS - 1 ? 0 : st + 1;
   }
-  if constexpr (DBUF) {
+  if constexpr (DBUF && !STATS) {
     __syncthreads();
     if (jj > 0) store_tile(prev_bm0, sC + ((jj - 1) & 1) * C_BYTES);
   }
@@ -245,13 +247,15 @@ __global__ __launch_bounds__(512) void conv1x1_stream_kernel(const StreamDesc d)
   }
 }
 
-template <int BN, int KT, bool ABN>
+template <int BN, int KT, bool ABN, bool STATS = false>
 bool launch_stream(const StreamDesc& sd, hipStream_t stream) {
   constexpr int NS = KT == 1 ? 4 : 2;
-  constexpr size_t lds = (size_t)NS * KT * 128 * 128 + (size_t)KT * BN * 128 + (KT == 1 ? 2 : 1) * 128 * (BN * 2 + 16) + 4 * BN * 2 * 4 + (ABN ? 64 * KT * 8 : 0);
+  constexpr size_t lds = (size_t)NS * KT * 128 * 128 + (size_t)KT * BN * 128 + (STATS ? 0 : (KT == 1 ? 2 : 1) * 128 * (BN * 2 + 16)) + 4 * BN * 2 * 4 +
+                         (ABN ? 64 * KT * 8 : 0);
+  static_assert(lds <= 160 * 1024, "conv1x1_stream LDS budget");
   static LdsGrant granted;
-  if (!grant_lds(conv1x1_stream_kernel<BN, KT, ABN>, lds, granted)) return false;
-  hipLaunchKernelGGL((conv1x1_stream_kernel<BN, KT, ABN>), dim3((unsigned)(sd.groups * sd.tiles_n)), dim3(512), lds, stream, sd);
+  if (!grant_lds(conv1x1_stream_kernel<BN, KT, ABN, STATS>, lds, granted)) return false;
+  hipLaunchKernelGGL((conv1x1_stream_kernel<BN, KT, ABN, STATS>), dim3((unsigned)(sd.groups * sd.tiles_n)), dim3(512), lds, stream, sd);
   return true;
 }
 
@@ -273,11 +277,14 @@ bool try_conv1x1_stream(const GemmDesc& d, hipStream_t stream) {
   static const bool bn64 = getenv("GIC_STREAM_BN64") != nullptr;
   static const int wg_per_cu = [] { const char* e = getenv("GIC_STREAM_WG_PER_CU"); return e ? atoi(e) : 1; }();
   const bool n128 = d.N >= 128 && !bn64;
+  // the statistics-only pass (input normalised on load, output channels a multiple of 256): 256 channels per workgroup
+  const bool stats256 = d.stats_only && abn && d.N % 256 == 0;
+  if (d.stats_only && !stats256) return false;
   StreamDesc sd;
   sd.tiles_m = cdiv(d.M, 128);
-  sd.tiles_n = n128 ? cdiv(d.N, 128) : cdiv(d.N, 64);
-  // streaming pays where a workgroup walks several row tiles; small grids stay with tile8
-  if ((long)sd.tiles_m * sd.tiles_n < min_tiles) return false;
+  sd.tiles_n = stats256 ? d.N / 256 : (n128 ? cdiv(d.N, 128) : cdiv(d.N, 64));
+  // streaming pays where a workgroup walks several row tiles; small grids stay with tile8 (counted in 128-wide tiles for both forms)
+  if ((long)sd.tiles_m * (stats256 ? d.N / 128 : sd.tiles_n) < min_tiles) return false;
   int groups = 256 * wg_per_cu / sd.tiles_n;           // one persistent workgroup per CU (the ring + the C tile fill most of its LDS)
   if (groups < 1) groups = 1;
   if (groups > sd.tiles_m) groups = sd.tiles_m;
@@ -289,6 +296,7 @@ bool try_conv1x1_stream(const GemmDesc& d, hipStream_t stream) {
   sd.stats_nrep = d.stats_nrep < 1 ? 1 : d.stats_nrep; sd.in_nrep = d.in_nrep; sd.in_inv_count = d.in_inv_count;
   sd.a_bytes = (unsigned)(a_elems * 2); sd.b_bytes = (unsigned)(b_elems * 2);
   const int kt = d.K / 64;
+  if (stats256) return kt == 1 ? launch_stream<256, 1, true, true>(sd, stream) : launch_stream<256, 2, true, true>(sd, stream);
   if (abn) {
     if (n128) return kt == 1 ? launch_stream<128, 1, true>(sd, stream) : launch_stream<128, 2, true>(sd, stream);
     return kt == 1 ? launch_stream<64, 1, true>(sd, stream) : launch_stream<64, 2, true>(sd, stream);
