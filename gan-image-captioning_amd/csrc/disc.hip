@@ -221,6 +221,88 @@ __global__ __launch_bounds__(512) void disc_conv_pool_fwd_mfma_kernel(const floa
   }
 }
 
+// ---- the forward-only form in the bf16 mode (reward evaluation of the SeqGAN-style step: no backward pass follows, no argmax is kept):
+// bf16 products on v_mfma_f32_32x32x16_bf16.  The fp32 kernel above is bound by the fp32 matrix pipe (one 16x16x4 product per 16 pairs x
+// 16 filters and time step: 123 of its 157 TFLOP/s); here one instruction forms 32 pairs x 32 filters of a time step with K = 16 >= the
+// filter width (rows of B beyond the width are zero, so the A window may run on into the next time steps), and the epilogue is one v_max
+// per element.  One workgroup = 32 (caption, representation) pairs: their embedding columns as bf16 windows xw[pair][t][0..7] =
+// x[pair][t .. t + 7] in LDS (one aligned 16-byte read per A fragment).  Values differ from the fp32 kernel's by bf16 rounding of the
+// embedding and the filter weights (the reward path already runs its highway layer and head in bf16).
+template <typename TA>
+__global__ __launch_bounds__(512) void disc_conv_pool_fwd_bf16_kernel(const float* __restrict__ emb, ConvMeta cm, int L, int De, int R, long rowsBR,
+                                                                        TA* __restrict__ pooled) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  // dynamic LDS: the windows xw [32 pairs][L][8] bf16, then the fp32 staging xs [32][TP] with TP = L + 9 (8 of zero overhang, odd pitch)
+  extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
+  const int TP = L + 9;
+  bf16_t* xwp = (bf16_t*)cp_smem;
+  float* xsp = (float*)(cp_smem + (size_t)32 * L * 16);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const long br0 = (long)blockIdx.x * 32;
+  for (int i = tid; i < 32 * TP; i += 512) {
+    const int p = i / TP, t = i - p * TP;
+    const long br = br0 + p;
+    float v = 0.f;
+    if (br < rowsBR && t < L) v = emb[((br / R) * L + t) * De + (br % R)];       // s == 1: representation r reads embedding column r
+    xsp[p * TP + t] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < 32 * L; i += 512) {
+    const int p = i / L, t = i - p * L;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)xsp[p * TP + t + e];
+    *(bf16x8*)(xwp + ((long)p * L + t) * 8) = v;
+  }
+  __syncthreads();
+  int tile = 0;
+  for (int k = 0; k < cm.nconv; ++k) {
+    const int f = cm.fsize[k], nf = cm.nfilt[k], T = L - f + 1;
+    const float* wk = cm.w[k];
+    const float* bk = cm.b[k];
+    for (int c0 = 0; c0 < nf; c0 += 32, ++tile) {
+      if ((tile & 7) != w) continue;                             // wave-uniform
+      const int ch = c0 + li;
+      const bool ok = ch < nf;
+      // B fragment: lane (filter li, k half lh) holds w[filter][8 lh .. 8 lh + 7]: the taps in the lower half, zero beyond the width
+      bf16x8 fb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fb[e] = (bf16_t)((ok && lh == 0 && e < f) ? wk[(long)ch * f + e] : 0.f);
+      const float bias = ok ? bk[ch] : 0.f;
+      f32x16 best;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) best[i] = 0.f;                // relu, then max over time: a running maximum that starts at 0
+      for (int t0 = 0; t0 < T; t0 += 2) {                        // two time steps together: independent accumulators
+        f32x16 a0, a1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a0[i] = a1[i] = bias;
+        const bf16x8 fa0 = *(const bf16x8*)(xwp + ((long)li * L + t0) * 8);
+        const bf16x8 fa1 = *(const bf16x8*)(xwp + ((long)li * L + (t0 + 1 < T ? t0 + 1 : t0)) * 8);   // (an odd T repeats its last step: the maximum is unchanged)
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb, a1, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) best[i] = fmaxf(best[i], fmaxf(a0[i], a1[i]));
+      }
+      // accumulator register i: pair 8 (i / 4) + 4 lh + (i % 4), column li = filter
+      if (ok) {
+        const int col = cm.foff[k] + ch;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const long br = br0 + 8 * (i >> 2) + 4 * lh + (i & 3);
+          if (br < rowsBR) pooled[br * cm.Fp + col] = from_f32<TA>(best[i]);
+        }
+      }
+    }
+  }
+  // pad columns F .. Fp-1 (zero, as the other kernels write them)
+  for (int i = tid; i < 32 * (cm.Fp - cm.F); i += 512) {
+    const int p = i / (cm.Fp - cm.F), c = cm.F + i % (cm.Fp - cm.F);
+    const long br = br0 + p;
+    if (br < rowsBR) pooled[br * cm.Fp + c] = from_f32<TA>(0.f);
+  }
+}
+
 // ---- conv backward, input side: d emb.  One block per (b, r) owns its s embedding columns.
 template <typename TA>
 __global__ __launch_bounds__(256) void disc_conv_pool_bwd_x_kernel(const float* __restrict__ dpooled, const TA* __restrict__ pooled,
@@ -603,7 +685,12 @@ int disc_fwd_t(const DCtx& c, const gic_disc_params* P, const gic_disc_shadow* S
   int max_taps = 0;
   for (int k = 0; k < c.cm.nconv; ++k) max_taps = c.cm.fsize[k] * c.s > max_taps ? c.cm.fsize[k] * c.s : max_taps;
   static const bool no_mfma = getenv("GIC_NO_DISC_CONV_MFMA") != nullptr;
-  if (c.s == 1 && max_taps <= 8 && !no_mfma)
+  static const bool no_bf16 = getenv("GIC_NO_DISC_CONV_BF16") != nullptr;
+  if (c.s == 1 && max_taps <= 8 && !no_mfma && !no_bf16 && sizeof(TA) == 2 && !st->argmax && c.L <= 64)
+    hipLaunchKernelGGL((disc_conv_pool_fwd_bf16_kernel<TA>), dim3((unsigned)((c.rowsBR + 31) / 32)), dim3(512),
+                       (size_t)32 * c.L * 16 + (size_t)32 * (c.L + 9) * 4, stream,
+                       (const float*)st->emb, c.cm, c.L, c.De, c.R, c.rowsBR, (TA*)st->pooled);
+  else if (c.s == 1 && max_taps <= 8 && !no_mfma)
     hipLaunchKernelGGL((disc_conv_pool_fwd_mfma_kernel<TA>), dim3((unsigned)((c.rowsBR + 15) / 16)), dim3(512), 0, stream,
                        (const float*)st->emb, c.cm, c.L, c.De, c.R, c.rowsBR, (TA*)st->pooled, st->argmax);
   else if (max_taps <= 8)

@@ -560,6 +560,33 @@ def test_bf16_discriminator_at_bench_batch(E, dev):
     assert torch.equal(st1["ydrop"], st3["ydrop"])
 
 
+def test_forward_only_discriminator_convolution_in_bf16_matches_the_fp32_kernels(E, dev):
+    """The reward-evaluation form of Discriminator.forward (eval mode, nothing kept for a backward pass) runs its convolution + ReLU +
+    max-over-time with bf16 products on the 32x32x16 MFMA (disc.hip); the same forward WITH a saved state runs the fp32-product kernel
+    (discriminator.py:40-47 as the reference computes it).  Same parameters and ids, 70 captions x 64 representations (a partial
+    32-pair workgroup at the end), odd and even window counts: pooled features agree to bf16 rounding of the embedding and the
+    filter weights, logits to the bf16 budget of the rest of the reward path, and both stay close to the fp32 oracle."""
+    g = Golden("cfg1")
+    _, dp = initial_params(g)
+    m = g.meta
+    B, Lc, V = 70, 13, m["V"]
+    rg = torch.Generator().manual_seed(33)
+    ids = torch.randint(0, V, (B, Lc), generator=rg)
+    deng = _disc(E, m, 1)
+    dparams = disc_params(dp, dev)
+    lg_keep, st_keep = deng.fwd(dparams, None, ids.to(dev), False)
+    lg_fwd, st_fwd = deng.fwd(dparams, None, ids.to(dev), False, forward_only=True)
+    torch.cuda.synchronize()
+    F = sum(m["nf"])
+    assert st_fwd["argmax"] is None and st_keep["argmax"] is not None
+    pk, pf = st_keep["pooled"][:, :F].float(), st_fwd["pooled"][:, :F].float()
+    assert float(st_fwd["pooled"][:, F:].abs().max() if deng.Fp > F else 0.0) == 0.0
+    assert rel_l2(pf, pk) < 1e-2, rel_l2(pf, pk)
+    assert float((pf - pk).abs().max()) <= 4e-2 * float(pk.abs().max())
+    want = O.disc_forward(dp, torch.nn.functional.one_hot(ids, V).float(), None, m["R"])
+    assert rel_l2(lg_keep, want) < 2e-2 and rel_l2(lg_fwd, want) < 3e-2, (rel_l2(lg_keep, want), rel_l2(lg_fwd, want))
+
+
 def test_no_cpu_fallback(E):
     """The product path refuses CPU tensors instead of silently computing elsewhere."""
     from gan_image_captioning_amd._lib import GicError
