@@ -577,13 +577,20 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None, 
     seen = {}
     per_layer_step_ms = {}
     for s, xi, yo, H, W, kw, macs, prev in plan.conv_shapes(N, S):
-        mode = 0 if (prev is None or not s.fused_in) else (2 if prev[0] == "res" else 1)
-        key = (s.cin, s.cout, s.k, s.stride, H, mode + (10 if (mode == 2 and prev[1][3] is not None) else 0))
+        mode = 0
+        if prev is not None and prev[0] == "b2b":
+            mode = 3                   # conv3 recomputed + block output + this conv1 in one launch (gic_conv_b2b)
+        elif prev is not None and prev[0] == "b2bstats":
+            mode = 4                   # conv3's column sums only (the first pass of that pair)
+        elif prev is not None and s.fused_in:
+            mode = 2 if prev[0] == "res" else 1
+        key = (s.cin, s.cout, s.k, s.stride, H, mode + (10 if (mode in (2, 3) and prev[1][4 if mode == 3 else 3] is not None) else 0))
         if key not in seen:
             seen[key] = [event_time_ms(lambda: plan.replay(s, xi, yo, b["stats"], N, H, W, kw, prev), 5, stream), 0, macs,
-                         s.name + {0: "", 1: " [bn+relu on load]", 2: " [block output on load]", 12: " [block output on load, proj.]"}[key[5]], 0.0,
+                         s.name + {0: "", 1: " [bn+relu on load]", 2: " [block output on load]", 12: " [block output on load, proj.]",
+                                   3: " [conv3 + block output + conv1]", 13: " [conv3 + block output + conv1, proj.]", 4: " [statistics only]"}[key[5]], 0.0,
                          # the same layer as a plain convolution of an already normalised input (what the fused launches replaced)
-                         event_time_ms(lambda: plan.replay(s, xi, yo, b["stats"], N, H, W, kw, None), 5, stream) if mode else None]
+                         event_time_ms(lambda: plan.replay(s, xi, yo, b["stats"], N, H, W, kw, None), 5, stream) if mode in (1, 2) else None]
         seen[key][1] += 1
         if in_step and s.name in in_step["in_step"]:
             v, a0 = in_step["in_step"][s.name], in_step["alone"].get(s.name)
@@ -604,6 +611,10 @@ def roofline_probe(encoder, args, event_time_ms, peak_tflops, pmc_traffic=None, 
         nbytes = 2.0 * (N * key[4] * key[4] * key[0] + N * Ho * Ho * key[1] + key[0] * key[1] * key[2] * key[2])
         if key[5] in (2, 12):          # block output formed on load: + the shortcut tensor read and the block output written back
             nbytes += 2.0 * 2 * N * key[4] * key[4] * key[0]
+        elif key[5] in (3, 13):        # back to back: the "input" counted above is the shortcut; + the block output written, + y2 (a quarter of the channels) read
+            nbytes += 2.0 * 1.25 * N * key[4] * key[4] * key[0]
+        elif key[5] == 4:              # statistics only: nothing is written
+            nbytes -= 2.0 * N * Ho * Ho * key[1]
         floor_us = max(2.0 * macs / (peak_tflops * 1e12), nbytes / 8e12) * 1e6
         bound_us += floor_us * count
         total_bytes += nbytes * count
