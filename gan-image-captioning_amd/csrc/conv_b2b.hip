@@ -35,21 +35,41 @@ __device__ __forceinline__ u32x4 buf_load16(const __amdgpu_buffer_rsrc_t r, cons
   return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
 }
 __device__ __forceinline__ void buf_store16(const u32x4 v, const __amdgpu_buffer_rsrc_t r, const int voff, const int soff) {
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+  // The tile offset rides in the per-lane offset, not in the scalar one: the compiler (hipcc 7.2) assumes a store of more than 8 bytes
+  // with an SGPR offset needs no wait state before a VALU instruction overwrites its data registers and schedules one right behind
+  // it; on gfx950 that instruction's result reached memory in place of the first dword (sporadically, lanes 12-15 of each row of 16).
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + soff, 0, 0);
 }
+
+// Lane l's value of its neighbour l ^ X inside its row of 16 lanes, on the VALU (DPP: fused into the addition that consumes it).
+// __shfl_xor is ds_bpermute_b32 -- an LDS instruction: 30 of them per reduce-scatter pair in four dependent stages, queued behind the
+// weight fragment reads of all eight waves.
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(const float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_xor8(const float v) { return row_dpp<0x128>(v); }                  // row_ror:8
+__device__ __forceinline__ float row_xor4(const float v) {                                              // lanes with bit 2 clear read l + 4 (row_ror:12,
+  const int x = __builtin_bit_cast(int, v);                                                             // banks 0 and 2), the others l - 4 (row_ror:4)
+  int a = __builtin_amdgcn_update_dpp(0, x, 0x12C, 0xF, 0x5, false);
+  a = __builtin_amdgcn_update_dpp(a, x, 0x124, 0xF, 0xA, false);
+  return __builtin_bit_cast(float, a);
+}
+__device__ __forceinline__ float row_xor2(const float v) { return row_dpp<0x4E>(v); }                   // quad_perm:[2,3,0,1]
+__device__ __forceinline__ float row_xor1(const float v) { return row_dpp<0xB1>(v); }                   // quad_perm:[1,0,3,2]
 
 // Sum over the 16 lanes of a row (lr) of 16 per-lane values, value e ending up in lane lr == e: a reduce-scatter butterfly, 15 lane
 // exchanges and 15 additions instead of 16 separate registers that live across the whole kernel.
 __device__ __forceinline__ float row_reduce_scatter16(const float (&v)[16], const int lr) {
   float t[8], u[4], x[2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { const bool up = lr & 8; t[i] = (up ? v[i + 8] : v[i]) + __shfl_xor(up ? v[i] : v[i + 8], 8, 64); }
+  for (int i = 0; i < 8; ++i) { const bool up = lr & 8; t[i] = (up ? v[i + 8] : v[i]) + row_xor8(up ? v[i] : v[i + 8]); }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { const bool up = lr & 4; u[i] = (up ? t[i + 4] : t[i]) + __shfl_xor(up ? t[i] : t[i + 4], 4, 64); }
+  for (int i = 0; i < 4; ++i) { const bool up = lr & 4; u[i] = (up ? t[i + 4] : t[i]) + row_xor4(up ? t[i] : t[i + 4]); }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) { const bool up = lr & 2; x[i] = (up ? u[i + 2] : u[i]) + __shfl_xor(up ? u[i] : u[i + 2], 2, 64); }
+  for (int i = 0; i < 2; ++i) { const bool up = lr & 2; x[i] = (up ? u[i + 2] : u[i]) + row_xor2(up ? u[i] : u[i + 2]); }
   const bool up = lr & 1;
-  return (up ? x[1] : x[0]) + __shfl_xor(up ? x[0] : x[1], 1, 64);
+  return (up ? x[1] : x[0]) + row_xor1(up ? x[0] : x[1]);
 }
 
 // C2: channels of y2 (64 | 128); C1N: output channels of the next conv1 (64 | 128); IDENT: identity shortcut (no BatchNorm of its own)

@@ -15,6 +15,7 @@
 #include "conv3x3.h"
 #include "conv1x1_stream.h"
 #include "conv1x1_panel.h"
+#include "conv1x1_pix.h"
 #include "conv_stem.h"
 #include "bn_fold.h"
 
@@ -1250,6 +1251,8 @@ int pick_conv(const GemmDesc& d, hipStream_t stream) {
     // shallow 1x1 layers over many rows: persistent workgroups, resident weights, A tiles streamed across row tiles (conv1x1_stream.hip)
     if (try_conv1x1_stream(d, stream)) { GIC_CHECK_LAUNCH("conv1x1 stream"); return GIC_OK; }
     if (d.stats_only) return GIC_ERR_UNSUPPORTED;               // (no message: callers probe)
+    // K = 256 | 512 of a normalised input into many output channels: the pixels in registers, weight tiles streamed (conv1x1_pix.hip)
+    if (try_conv1x1_pix(d, stream)) { GIC_CHECK_LAUNCH("conv1x1 pix"); return GIC_OK; }
     // K = 256 into many output channels: the A panel of a row tile loaded / normalised once for all its channel tiles (conv1x1_panel.hip)
     if (try_conv1x1_panel(d, stream)) { GIC_CHECK_LAUNCH("conv1x1 panel"); return GIC_OK; }
     if (d.in_stats && d.cKH * d.cKW > 1) return GIC_ERR_UNSUPPORTED;
