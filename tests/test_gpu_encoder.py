@@ -527,6 +527,11 @@ def test_conv3_recomputed_inside_the_next_conv1_equals_the_separate_launches(dev
     print("block outputs rel L2:", report)
     for i, e in enumerate(errs):
         assert e < (2e-2 if i < 7 else 1e-1), f"block {i} output: {report}"
+    # ... and element by element where the two forms differ by rounding only (the first boundary): a 16-byte store whose data registers
+    # were overwritten one instruction later put a stray value into two bytes of a few rows -- invisible in an L2 norm
+    a, b_ = outs[True][1][0], outs[False][1][0]
+    stray = int(((a - b_).abs() > 0.25 + 0.05 * b_.abs()).sum())
+    assert stray == 0, f"{stray} stray elements in the first fused block output (max |diff| {float((a - b_).abs().max()):.3f})"
     assert rel_l2(outs[True][0], outs[False][0]) < 3e-2, report
     assert rel_l2(outs[True][3], outs[False][3]) < 1e-2 and rel_l2(outs[True][4], outs[False][4]) < 5e-2, report
 
@@ -593,6 +598,44 @@ def test_cold_and_mispredicted_trunk_passes_do_not_race_the_lookahead(dev):
             err = rel_l2(got.float(), ref[want])
             assert err < 2e-2, f"rep {rep}: features of batch {want} corrupted (rel L2 {err:.3e})"     # f32-atomic BatchNorm sums: not bit-exact
         assert tA.data_ptr() != tA2.data_ptr() and tA.data_ptr() != enc.resnet._plan._bufs[(32, 224)]["feat"].data_ptr()
+
+
+@pytest.mark.parametrize("N", [64, 33, 5])
+def test_pixel_resident_conv3_every_element(dev, N):
+    """conv1x1_pix.hip (K = 256 into 1024 channels on the 14 x 14 map, BatchNorm + ReLU of the input on load, pixels in registers,
+    32-byte stores from the accumulators) against a float matmul, EVERY element to bf16 rounding, and its column sums: full row tiles
+    (64 images), a ragged last tile (33, 5).  The first version passed every norm-based check with 1e-4 of its elements replaced by
+    stray values (a VALU instruction overwrote a store's data registers one instruction behind it)."""
+    from gan_image_captioning_amd import engine
+    L = _lib()
+    lib = L.load()
+    H, Ci, Co = 14, 256, 1024
+    rows = N * H * H
+    g = torch.Generator().manual_seed(N)
+    y = (torch.randn(rows, Ci, generator=g) * 1.5 + 0.3).to(dev).bfloat16()
+    w = (torch.randn(Co, Ci, generator=g) * 0.05).to(dev).bfloat16()
+    gamma = (torch.rand(Ci, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(Ci, generator=g) * 0.2).to(dev)
+    yf = y.float()
+    nrep = 4
+    in_stats = torch.zeros(nrep, 2 * Ci, device=dev)
+    in_stats[3, :Ci] = yf.sum(0)
+    in_stats[0, Ci:] = (yf * yf).sum(0)
+    mean = yf.mean(0)
+    var = ((yf * yf).mean(0) - mean * mean).clamp_min(0)
+    sc = gamma * torch.rsqrt(var + 1e-5)
+    z = torch.relu(yf * sc + (beta - mean * sc)).bfloat16().float()       # the operand the MFMAs see
+    ref = z @ w.float().t()
+    out = torch.full((rows, Co), 7.0, device=dev, dtype=torch.bfloat16)
+    st = torch.zeros(nrep, 2 * Co, device=dev)
+    L.check(lib.gic_conv2d_bn_in(y.data_ptr(), in_stats.data_ptr(), nrep, gamma.data_ptr(), beta.data_ptr(), float(rows), w.data_ptr(),
+                                 out.data_ptr(), st.data_ptr(), nrep, 1, N, H, H, Ci, Co, 1, 1, 1, 0, engine.stream_ptr()), "conv2d_bn_in")
+    torch.cuda.synchronize()
+    o = out.float()
+    bad = (o - ref).abs() > 2e-2 + 1.5e-2 * ref.abs()                     # bf16 rounding of the output + of a few normalised inputs
+    assert int(bad.sum()) == 0, (int(bad.sum()), bad.any(1).nonzero().flatten()[:8].tolist(), bad.any(0).nonzero().flatten()[:8].tolist())
+    torch.testing.assert_close(st.sum(0)[:Co], ref.sum(0), rtol=2e-3, atol=2e-2 * rows ** 0.5)
+    torch.testing.assert_close(st.sum(0)[Co:], (ref * ref).sum(0), rtol=2e-3, atol=2e-2 * rows ** 0.5)
 
 
 @pytest.mark.parametrize("case", [(8, 28, 128, 512, 1, 1, 0), (4, 56, 64, 256, 1, 1, 0), (16, 14, 256, 1024, 1, 1, 0), (2, 7, 512, 2048, 1, 1, 0),
