@@ -9,7 +9,7 @@ def is_trunk_conv(name: str) -> bool:
     CONV = true only -- the other tile8 instantiations are the discriminator's highway products (mangled: ...tile8_kernelIDF16bLi128ELi1ELb0E...;
     demangled: tile8_kernel<float, 128, 0, false, ...>)."""
     if any(k in name for k in ("conv3x3_patch_kernel", "conv1x1_stream_kernel", "conv1x1_panel_kernel", "conv_stem_kernel", "conv3x3_s2_kernel",
-                               "conv1x1_small_kernel", "conv_b2b_kernel")):
+                               "conv1x1_small_kernel", "conv_b2b_kernel", "conv1x1_pix_kernel")):
         return True
     if "tile8_kernel" not in name:
         return False
