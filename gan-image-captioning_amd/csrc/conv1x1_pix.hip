@@ -27,7 +27,11 @@ __device__ __forceinline__ void pix_store16(const u32x4 v, const __amdgpu_buffer
   // The tile offset rides in the per-lane offset, not in the scalar one: the compiler (hipcc 7.2) assumes a store of more than 8 bytes
   // with an SGPR offset needs no wait state before a VALU instruction overwrites its data registers and schedules one right behind
   // it; on gfx950 that instruction's result reached memory in place of the first dword (sporadically, lanes 12-15 of each row of 16).
+#ifdef GIC_STORE_SOFF                                                      // (measurement build: the form that exposes the hazard)
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+#else
   __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + soff, 0, 0);
+#endif
 }
 struct PixDesc {
   const void* A; const void* B; void* C; float* stats;

@@ -517,9 +517,11 @@ def test_conv3_recomputed_inside_the_next_conv1_equals_the_separate_launches(dev
         feat = trunk(images, 1).float().clone()
         torch.cuda.synchronize()
         blocks = [e["out"].float().clone() for e in plan._bufs[(64, 224)]["blocks"]]
+        y1_first = plan._bufs[(64, 224)]["blocks"][1]["y1"].float().clone()     # conv1 of the second block: the first fused launch's other output
+        y1_last = plan._bufs[(64, 224)]["blocks"][7]["y1"].float().clone()      # conv1 of block 6.0: the last one's (C2 = 128 into 256 channels)
         nb2b = sum(1 for blk in plan.blocks if blk.get("b2b") is True)
         sd = trunk.state_dict()
-        outs[fused] = (feat, blocks, nb2b, sd["5.1.bn1.running_var"].float().clone(), sd["7.2.bn3.running_var"].float().clone())
+        outs[fused] = (feat, blocks, nb2b, sd["5.1.bn1.running_var"].float().clone(), sd["7.2.bn3.running_var"].float().clone(), y1_first, y1_last)
     assert outs[True][2] == 7 and outs[False][2] == 0, (outs[True][2], outs[False][2])
     errs = [rel_l2(a, b_) for a, b_ in zip(outs[True][1], outs[False][1])]
     report = " ".join(f"{e:.2e}" for e in errs) + (f" | pooled {rel_l2(outs[True][0], outs[False][0]):.2e} running_var "
@@ -527,11 +529,15 @@ def test_conv3_recomputed_inside_the_next_conv1_equals_the_separate_launches(dev
     print("block outputs rel L2:", report)
     for i, e in enumerate(errs):
         assert e < (2e-2 if i < 7 else 1e-1), f"block {i} output: {report}"
-    # ... and element by element where the two forms differ by rounding only (the first boundary): a 16-byte store whose data registers
-    # were overwritten one instruction later put a stray value into two bytes of a few rows -- invisible in an L2 norm
-    a, b_ = outs[True][1][0], outs[False][1][0]
-    stray = int(((a - b_).abs() > 0.25 + 0.05 * b_.abs()).sum())
-    assert stray == 0, f"{stray} stray elements in the first fused block output (max |diff| {float((a - b_).abs().max()):.3f})"
+    # ... and element by element: a 16-byte store whose data registers are overwritten one instruction later can put a stray value into
+    # two bytes of a few rows -- invisible in an L2 norm (seen in conv1x1_pix.hip; conv_b2b_kernel<128, 256> had two such sites, which
+    # a measurement build -DGIC_STORE_SOFF brings back: no stray element was observed there, the check stays as the guard)
+    for what, k, a, b_ in (("first fused launch's block output", 0.25, outs[True][1][0], outs[False][1][0]),
+                           ("first fused launch's conv1 output", 0.25, outs[True][5], outs[False][5]),
+                           ("last fused launch's conv1 output", 0.5, outs[True][6], outs[False][6])):
+        scale = float(b_.abs().mean())
+        stray = int(((a - b_).abs() > k * scale + 0.05 * b_.abs()).sum())
+        assert stray == 0, f"{stray} stray elements in the {what} (max |diff| {float((a - b_).abs().max()):.3f}, mean |value| {scale:.3f})"
     assert rel_l2(outs[True][0], outs[False][0]) < 3e-2, report
     assert rel_l2(outs[True][3], outs[False][3]) < 1e-2 and rel_l2(outs[True][4], outs[False][4]) < 5e-2, report
 
@@ -605,7 +611,7 @@ def test_pixel_resident_conv3_every_element(dev, N):
     """conv1x1_pix.hip (K = 256 into 1024 channels on the 14 x 14 map, BatchNorm + ReLU of the input on load, pixels in registers,
     32-byte stores from the accumulators) against a float matmul, EVERY element to bf16 rounding, and its column sums: full row tiles
     (64 images), a ragged last tile (33, 5).  The first version passed every norm-based check with 1e-4 of its elements replaced by
-    stray values (a VALU instruction overwrote a store's data registers one instruction behind it)."""
+    stray values (a VALU instruction overwrote a store's data registers one instruction behind it: DESIGN.md section 4)."""
     from gan_image_captioning_amd import engine
     L = _lib()
     lib = L.load()
