@@ -1,14 +1,16 @@
-// 1x1 convolutions with K = 256 / 512 input channels into many output channels on the SMALL maps (conv3 of the 14x14 and 7x7
-// bottlenecks of the ResNet trunk, reference src/generator.py:12-14), with the PIXELS resident in registers (round 3).
+// conv3 of the 14x14 bottlenecks of the ResNet trunk (1x1, K = 256 input channels into 1024, BatchNorm + ReLU of the input on load;
+// reference src/generator.py:12-14) with the PIXELS resident in registers (round 3).
 //
 // The panel kernel (conv1x1_panel.hip) keeps the A panel of a 128-row tile in LDS and runs its output-channel tiles through a
 // two-stage weight ring; per 64-channel tile it pays fragment reads of BOTH operands, a C tile staged through LDS (2-byte writes),
-// a second barrier and the row stores: 21 us per launch against an HBM floor of 4.  Here the products are transposed as in
+// a second barrier and the row stores: 21-25 us per launch against an HBM floor of 4.  Here the products are transposed as in
 // conv_b2b.hip: a wave owns 16 pixels, their K channels are the MFMA B operand and stay in registers (K / 32 fragments per lane,
-// loaded from global memory once and normalised there), the weights are the A operand and are the only thing in LDS (a three- or
-// two-stage LDS-DMA ring of 64-channel tiles, rows laid out so that a lane ends up with 16 CONSECUTIVE output channels of its
-// pixel): 32-byte stores straight from the accumulators, one barrier per tile, no C tile.  The BatchNorm column sums of a tile are
-// folded across the wave's 16 pixels by the reduce-scatter butterfly of conv_b2b.hip and collected per workgroup in LDS.
+// loaded from global memory once and normalised there), the weights are the A operand and are the only thing in LDS (a three-stage
+// LDS-DMA ring of 64-channel tiles, rows laid out so that a lane ends up with 16 CONSECUTIVE output channels of its pixel): 32-byte
+// stores straight from the accumulators, one barrier per tile, no C tile.  The BatchNorm column sums of a tile: the wave's 64 x 16
+// tile is turned through a private LDS scratch (lane c then holds channel c of all 16 pixels), summed, kept in registers per tile and
+// folded across the eight waves once at the end (what the butterfly and the LDS atomics of the first versions cost).
+// The template is written for K = 256 | 512; only K = 256 is instantiated (two 64 KB stages for K = 512 do not fit beside the scratch).
 #include <stdlib.h>
 
 #include "conv1x1_pix.h"
@@ -42,7 +44,7 @@ struct PixDesc {
   unsigned a_bytes, b_bytes, c_bytes;
 };
 
-// K input channels (256 | 512); NSTG ring stages of 64-channel weight tiles
+// K input channels; NSTG ring stages of 64-channel weight tiles
 template <int K, int NSTG>
 __global__ __launch_bounds__(512) void conv1x1_pix_kernel(const PixDesc d) {
   constexpr int NT = 512, KS = K / 32;
