@@ -1,5 +1,5 @@
-// conv3 of the 14x14 bottlenecks of the ResNet trunk (1x1, K = 256 input channels into 1024, BatchNorm + ReLU of the input on load;
-// reference src/generator.py:12-14) with the PIXELS resident in registers (round 3).
+// conv3 of the 14x14 and 7x7 bottlenecks of the ResNet trunk (1x1, K = 256 input channels into 1024 / K = 512 into 2048, BatchNorm +
+// ReLU of the input on load; reference src/generator.py:12-14) with the PIXELS resident in registers (round 3).
 //
 // The panel kernel (conv1x1_panel.hip) keeps the A panel of a 128-row tile in LDS and runs its output-channel tiles through a
 // two-stage weight ring; per 64-channel tile it pays fragment reads of BOTH operands, a C tile staged through LDS (2-byte writes),
@@ -10,7 +10,7 @@
 // stores straight from the accumulators, one barrier per tile, no C tile.  The BatchNorm column sums of a tile: the wave's 64 x 16
 // tile is turned through a private LDS scratch (lane c then holds channel c of all 16 pixels), summed, kept in registers per tile and
 // folded across the eight waves once at the end (what the butterfly and the LDS atomics of the first versions cost).
-// The template is written for K = 256 | 512; only K = 256 is instantiated (two 64 KB stages for K = 512 do not fit beside the scratch).
+// K = 512: two 64 KB stages leave no room for the scratch; its column sums take the reduce-scatter butterfly of conv_b2b.hip on DPP.
 #include <stdlib.h>
 
 #include "conv1x1_pix.h"
@@ -35,6 +35,30 @@ __device__ __forceinline__ void pix_store16(const u32x4 v, const __amdgpu_buffer
   __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + soff, 0, 0);
 #endif
 }
+// lane l's value of its row-of-16 neighbour l ^ X on the VALU (DPP), and the reduce-scatter butterfly of conv_b2b.hip on them: the
+// column sums where the turning scratch does not fit the LDS (K = 512)
+template <int CTRL>
+__device__ __forceinline__ float pix_dpp(const float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float pix_xor4(const float v) {                 // lanes with bit 2 clear read l + 4 (row_ror:12, banks 0 and 2), the others l - 4
+  const int x = __builtin_bit_cast(int, v);
+  int a = __builtin_amdgcn_update_dpp(0, x, 0x12C, 0xF, 0x5, false);
+  a = __builtin_amdgcn_update_dpp(a, x, 0x124, 0xF, 0xA, false);
+  return __builtin_bit_cast(float, a);
+}
+__device__ __forceinline__ float pix_reduce_scatter16(const float (&v)[16], const int lr) {   // sum over the row's 16 lanes, value e landing in lane lr == e
+  float t[8], u[4], x[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const bool up = lr & 8; t[i] = (up ? v[i + 8] : v[i]) + pix_dpp<0x128>(up ? v[i] : v[i + 8]); }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const bool up = lr & 4; u[i] = (up ? t[i + 4] : t[i]) + pix_xor4(up ? t[i] : t[i + 4]); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const bool up = lr & 2; x[i] = (up ? u[i + 2] : u[i]) + pix_dpp<0x4E>(up ? u[i] : u[i + 2]); }
+  const bool up = lr & 1;
+  return (up ? x[1] : x[0]) + pix_dpp<0xB1>(up ? x[0] : x[1]);
+}
+
 struct PixDesc {
   const void* A; const void* B; void* C; float* stats;
   const float* in_stats; const float* in_gamma; const float* in_beta;
@@ -44,8 +68,8 @@ struct PixDesc {
   unsigned a_bytes, b_bytes, c_bytes;
 };
 
-// K input channels; NSTG ring stages of 64-channel weight tiles
-template <int K, int NSTG>
+// K input channels; NSTG ring stages of 64-channel weight tiles; TURN: column sums through the turning scratch (else: DPP butterfly)
+template <int K, int NSTG, bool TURN>
 __global__ __launch_bounds__(512) void conv1x1_pix_kernel(const PixDesc d) {
   constexpr int NT = 512, KS = K / 32;
   constexpr int ROWB = K * 2, CH = ROWB / 16;                            // bytes / 16-byte pieces of a weight row
@@ -164,6 +188,8 @@ __global__ __launch_bounds__(512) void conv1x1_pix_kernel(const PixDesc d) {
     for (int e = 0; e < 16; ++e) o[e >> 3][e & 7] = (bf16_t)acc[e >> 2][e & 3];
     pix_store16(__builtin_bit_cast(u32x4, o[0]), rsC, coff, (nt0 + t) * 128);
     pix_store16(__builtin_bit_cast(u32x4, o[1]), rsC, coff + 16, (nt0 + t) * 128);
+    float s, q;
+    if constexpr (TURN) {
     // LDS traffic issued behind the compiler's back: it would make an LDS write it knows of wait for every LDS-DMA in flight
     // (may-alias), which is the ring this loop keeps ahead.  (Behind the stores: their conversions have read the accumulators.)
     asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\tds_write_b128 %0, %3 offset:32\n\tds_write_b128 %0, %4 offset:48"
@@ -177,9 +203,16 @@ __global__ __launch_bounds__(512) void conv1x1_pix_kernel(const PixDesc d) {
                  : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]),
                    "=&v"(x[10]), "=&v"(x[11]), "=&v"(x[12]), "=&v"(x[13]), "=&v"(x[14]), "=&v"(x[15])
                  : "v"(st_r));
-    float s = 0.f, q = 0.f;
+    s = 0.f; q = 0.f;
 #pragma unroll
     for (int p_ = 0; p_ < 16; ++p_) { s += x[p_]; q += x[p_] * x[p_]; }
+    } else {
+      // lane (lr, lg) ends up with the sums of channel 16 lg + lr = its lane index: the same slot the turned form fills
+      float vs[16], vq[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { vs[e] = acc[e >> 2][e & 3]; vq[e] = vs[e] * vs[e]; }
+      s = pix_reduce_scatter16(vs, lr); q = pix_reduce_scatter16(vq, lr);
+    }
     // kept in registers until the end (tile t's pair in slot t): LDS float atomics cost 9 of the first version's 29 us
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) { rs[i] = i == t ? s : rs[i]; rq[i] = i == t ? q : rq[i]; }
@@ -201,13 +234,13 @@ __global__ __launch_bounds__(512) void conv1x1_pix_kernel(const PixDesc d) {
   }
 }
 
-template <int K, int NSTG>
+template <int K, int NSTG, bool TURN>
 bool launch_pix(const PixDesc& pd, int groups, hipStream_t stream) {
-  const size_t lds = (size_t)NSTG * 64 * K * 2 + (size_t)K * 8 + 8 * 16 * 272;
+  const size_t lds = (size_t)NSTG * 64 * K * 2 + (size_t)K * 8 + (TURN ? 8 * 16 * 272 : 0);
   if (lds > 160 * 1024) return false;
   static LdsGrant granted;
-  if (!grant_lds(conv1x1_pix_kernel<K, NSTG>, lds, granted)) return false;
-  hipLaunchKernelGGL((conv1x1_pix_kernel<K, NSTG>), dim3((unsigned)(pd.tiles_m * groups)), dim3(512), lds, stream, pd);
+  if (!grant_lds(conv1x1_pix_kernel<K, NSTG, TURN>, lds, granted)) return false;
+  hipLaunchKernelGGL((conv1x1_pix_kernel<K, NSTG, TURN>), dim3((unsigned)(pd.tiles_m * groups)), dim3(512), lds, stream, pd);
   return true;
 }
 
@@ -218,7 +251,7 @@ bool try_conv1x1_pix(const GemmDesc& d, hipStream_t stream) {
   if (off || !d.conv || d.epi != EPI_BNSTATS || !d.stats || d.res || !d.in_stats) return false;      // (the input's BatchNorm rides in: conv3 of a bottleneck)
   if (d.in_dtype != DT_BF16 || d.out_dtype != DT_BF16) return false;
   if (d.cKH != 1 || d.cKW != 1 || d.cStride != 1 || d.cPad != 0) return false;
-  if (d.K != 256 || d.cCin != d.K || d.lda != d.K || d.ldb != d.K || d.N < 512 || d.N % 64 || d.ldc != d.N || d.M < 128) return false;
+  if ((d.K != 256 && d.K != 512) || d.cCin != d.K || d.lda != d.K || d.ldb != d.K || d.N < 512 || d.N % 64 || d.ldc != d.N || d.M < 128) return false;
   if ((((uintptr_t)d.C) & 15) || (((uintptr_t)d.A) & 15) || (((uintptr_t)d.B) & 15)) return false;
   if (d.bias || d.alpha != 1.f || d.accumulate || d.stats_only) return false;
   if (!d.in_gamma || !d.in_beta || d.in_inv_count <= 0.f || d.in_nrep < 1) return false;
@@ -239,7 +272,8 @@ bool try_conv1x1_pix(const GemmDesc& d, hipStream_t stream) {
   pd.in_stats = d.in_stats; pd.in_gamma = d.in_gamma; pd.in_beta = d.in_beta;
   pd.M = d.M; pd.N = d.N; pd.stats_nrep = d.stats_nrep < 1 ? 1 : d.stats_nrep; pd.in_nrep = d.in_nrep; pd.in_inv_count = d.in_inv_count;
   pd.a_bytes = (unsigned)a_bytes; pd.b_bytes = (unsigned)b_bytes; pd.c_bytes = (unsigned)c_bytes;
-  return launch_pix<256, 3>(pd, groups, stream);       // (K = 512 in two stages does not fit the LDS beside the turning scratch: tile8 keeps the 7 x 7 conv3)
+  // (K = 512: two 64 KB stages leave no room for the turning scratch: its column sums take the butterfly)
+  return d.K == 256 ? launch_pix<256, 3, true>(pd, groups, stream) : launch_pix<512, 2, false>(pd, groups, stream);
 }
 
 }  // namespace gic
